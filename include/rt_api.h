@@ -1,0 +1,266 @@
+/*
+ * rt_api.h — C ABI of the MI355X rendering core (librt_amd.so).
+ *
+ * The reference (doxxx/raytracer, Rust) has no FFI or plugin interface; the
+ * seam this library replaces is the call
+ *
+ *     system::render(options, scene, &mut progress)
+ *         reference src/main.rs:106  ->  src/system.rs:263-307
+ *
+ * A Rust host keeps its parser and scene API and adds one `flatten` pass that
+ * fills `rt_scene_desc` (INTEGRATION.md shows the `extern "C"` block and the
+ * build.rs a maintainer would add).  Everything crossing the boundary is plain
+ * pointers, sizes and PODs.  All functions return 0 on success or a negative
+ * `rt_status`; nothing unwinds or aborts across the boundary.  Pointers are
+ * borrowed for the duration of the call.  One `rt_scene` may be rendered from
+ * one thread at a time.
+ *
+ * Conventions follow the reference: f64 everywhere; points/directions are row
+ * vectors, `p * M` with translation in row 3 (src/matrix.rs:29-36,198-225);
+ * matrices are row-major double[16].
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / malformed scene description */
+    RT_ERR_PARSE = -2,       /* scene text does not match the grammar       */
+    RT_ERR_IO = -3,          /* file referenced by the scene not readable   */
+    RT_ERR_DEVICE = -4,      /* HIP runtime error (no GPU, OOM, launch)      */
+    RT_ERR_UNSUPPORTED = -5, /* scene exceeds a compiled-in device limit     */
+} rt_status;
+
+/* ---- scene description (what a host `flatten` pass produces) ------------ */
+
+/* Files under src/shapes: one node per `Shape` value, file order, children first or
+ * last does not matter (indices). */
+typedef enum rt_shape_kind {
+    RT_SHAPE_SPHERE = 0,        /* params: origin xyz, radius              (sphere.rs:12-25)   */
+    RT_SHAPE_PLANE = 1,         /* params: origin xyz, normal xyz          (plane.rs:34-56)    */
+    RT_SHAPE_XYRECT = 2,        /* params: origin xyz, width, height; flags bit0 = reverse (plane.rs:111-132) */
+    RT_SHAPE_XZRECT = 3,        /* same                                    (plane.rs:156-177)  */
+    RT_SHAPE_ZYRECT = 4,        /* same                                    (plane.rs:201-222)  */
+    RT_SHAPE_CUBE = 5,          /* params: p1 xyz, p2 xyz                  (cube.rs:20-37)     */
+    RT_SHAPE_CYLINDER = 6,      /* params: radius, height                  (cylinder.rs:12-25) */
+    RT_SHAPE_TORUS = 7,         /* params: radius1 (ring), radius2 (tube)  (torus.rs:13-26)    */
+    RT_SHAPE_UNION = 8,         /* child_a, child_b                        (csg.rs:7-21)       */
+    RT_SHAPE_INTERSECTION = 9,  /* child_a, child_b                        (csg.rs:112-126)    */
+    RT_SHAPE_DIFFERENCE = 10,   /* child_a, child_b                        (csg.rs:190-204)    */
+    RT_SHAPE_COMPOSITE = 11,    /* child_a = first entry in child_list, child_b = count (composite.rs:6-18) */
+    RT_SHAPE_MESH = 12,         /* child_a = mesh index; flags bit0 = smooth_shading (mesh.rs:11-52) */
+    RT_SHAPE_MEDIUM = 13,       /* child_a = boundary node; params[0] = density (homogenous_medium.rs:13-27) */
+} rt_shape_kind;
+
+typedef struct rt_shape_node {
+    int32_t kind;
+    int32_t child_a;
+    int32_t child_b;
+    int32_t flags;
+    double params[8];
+    double o2w[16]; /* Transformation::object_to_world (object.rs:7-26) */
+    double w2o[16]; /* Transformation::world_to_object = o2w.inverse()  */
+} rt_shape_node;
+
+typedef enum rt_material_kind {
+    RT_MAT_LAMBERTIAN = 0,    /* texture                (materials/lambertian.rs)    */
+    RT_MAT_METAL = 1,         /* fuzz, texture          (materials/metal.rs)         */
+    RT_MAT_DIELECTRIC = 2,    /* ior, fuzz              (materials/dielectric.rs)    */
+    RT_MAT_DIFFUSE_LIGHT = 3, /* intensity, texture     (materials/diffuse_light.rs) */
+    RT_MAT_ISOTROPIC = 4,     /* texture                (materials/isotropic.rs)     */
+} rt_material_kind;
+
+typedef struct rt_material {
+    int32_t kind;
+    int32_t texture; /* index into textures, -1 for dielectric */
+    double fuzz;
+    double ior;
+    double intensity;
+} rt_material;
+
+typedef enum rt_texture_kind {
+    RT_TEX_SOLID = 0,        /* c1                       (texture.rs:15)     */
+    RT_TEX_CHECKERBOARD = 1, /* c1, c2, scale            (texture.rs:72-90)  */
+    RT_TEX_IMAGE = 2,        /* image, scale             (texture.rs:59-67)  */
+} rt_texture_kind;
+
+typedef struct rt_texture {
+    int32_t kind;
+    int32_t image; /* index into images */
+    double c1[3];
+    double c2[3];
+    double scale;
+} rt_texture;
+
+typedef struct rt_image {
+    uint32_t width;
+    uint32_t height;
+    uint64_t offset; /* byte offset of the top-left RGB8 texel in image_data */
+} rt_image;
+
+/* One per wavefront `o` group (sdl.rs:65-92).  Indices in tri_v / tri_n are
+ * relative to first_vertex / first_normal. */
+typedef struct rt_mesh {
+    uint32_t first_vertex, n_vertices;
+    uint32_t first_normal, n_normals;
+    uint32_t first_triangle, n_triangles;
+} rt_mesh;
+
+typedef struct rt_object {
+    int32_t shape;    /* root node */
+    int32_t material; /* index into materials */
+} rt_object;
+
+/* Camera::new output (system.rs:37-55). */
+typedef struct rt_camera {
+    double fov_factor;          /* tan(fov/2) */
+    double camera_to_world[16]; /* rows: xaxis, yaxis, zaxis, origin */
+} rt_camera;
+
+typedef struct rt_scene_desc {
+    rt_camera camera;
+    double background[3]; /* SceneOptions::background_color (sdl.rs:24-34) */
+
+    uint32_t n_objects;
+    const rt_object *objects; /* file order: index = primary-hit id */
+    uint32_t n_nodes;
+    const rt_shape_node *nodes;
+    uint32_t n_child_list;
+    const int32_t *child_list;
+    uint32_t n_materials;
+    const rt_material *materials;
+    uint32_t n_textures;
+    const rt_texture *textures;
+    uint32_t n_images;
+    const rt_image *images;
+    uint64_t n_image_bytes;
+    const uint8_t *image_data;
+    uint32_t n_meshes;
+    const rt_mesh *meshes;
+    uint32_t n_vertices;
+    const double *vertices; /* xyz */
+    uint32_t n_normals;
+    const double *normals; /* xyz */
+    uint32_t n_triangles;
+    const uint32_t *tri_v; /* 3 per triangle */
+    const uint32_t *tri_n; /* 3 per triangle */
+} rt_scene_desc;
+
+/* ---- render options ------------------------------------------------------ */
+
+/* `Options` (system.rs:18-26) plus what the reference leaves implicit. */
+typedef struct rt_options {
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples;   /* `-s`; floor(sqrt(samples))^2 strata are rendered (system.rs:276-286) */
+    uint32_t max_depth; /* 50 in main.rs:86 */
+    double bias;        /* 1e-4 in main.rs:85 */
+    uint64_t seed;      /* rt_rng.h */
+    /* Tile sharding (multi-GPU): the image is cut into tile_size x tile_size
+     * tiles in row-major tile order; tile k belongs to shard k % shard_count. */
+    uint32_t tile_size;   /* multiple of 8; 0 -> 64 */
+    uint32_t shard_rank;  /* 0 .. shard_count-1 */
+    uint32_t shard_count; /* 0 -> 1 */
+    uint32_t flags;       /* reserved, 0 */
+} rt_options;
+
+typedef struct rt_stats {
+    uint64_t rays;         /* Ray::trace invocations, primary + secondary  */
+    uint64_t primary_rays; /* of which depth 0                             */
+    uint32_t strata;       /* strata rendered = floor(sqrt(samples))^2     */
+    uint32_t bounce_passes; /* intersect launches issued                   */
+    /* Situations in which the reference panics; the device
+     * treats them as a miss and counts them: cube >2 face hits, torus
+     * three-root mismatch, CSG "unanticipated difference case", cylinder
+     * asserts, NaN ordering. */
+    uint32_t guards[5];
+    uint32_t interval_overflow; /* CSG interval list exceeded device capacity */
+    double ms_device;           /* GPU time of the call, HIP events on its stream */
+} rt_stats;
+
+/* Nearest-hit record, one per ray: RayHit (system.rs:154-171). */
+typedef struct rt_hit {
+    double t; /* < 0 -> miss */
+    double n[3];
+    double uv[2];
+    int32_t object; /* -1 -> miss */
+    int32_t pad;
+} rt_hit;
+
+typedef struct rt_scene rt_scene;
+
+/* RenderProgress::sample_finished (system.rs:223-227): called on the calling
+ * thread after each stratum with the running-sum buffer (host, row-major
+ * [H][W][3]).  Return non-zero to stop early. */
+typedef int (*rt_progress_cb)(void *user, uint32_t strata_done, uint32_t strata_total, const double *rgb_sum);
+
+/* ---- device path --------------------------------------------------------- */
+
+/* Replaces the construction of RenderContext (system.rs:272-278): deep-copies
+ * the description onto the current HIP device, builds the per-mesh kd-tree and
+ * the flattened per-object CSG programs. */
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+/* Replaces system::render (system.rs:263-307) for a whole image on one GPU.
+ * rgb_sum: H*W*3 doubles, row-major, SUM over strata (not divided).
+ * primary_ids: H*W or NULL; object index of the primary hit in stratum 0,
+ * -1 for a miss.  stats, cb may be NULL. */
+int rt_render(rt_scene *scene, const rt_options *opts, double *rgb_sum, int32_t *primary_ids, rt_stats *stats,
+              rt_progress_cb cb, void *user);
+
+/* Same, for one shard of the tiles, on caller-provided DEVICE buffers and a
+ * caller-provided stream (hipStream_t, NULL = default).  Outputs are in shard
+ * layout: rt_shard_pixels(opts) entries, tile after tile (see
+ * rt_unshard_device).  Asynchronous on `stream` except for reading back the
+ * queue length every few bounces. */
+int rt_render_device(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,
+                     rt_stats *stats, void *stream);
+
+/* Number of pixel slots (padded to whole tiles) that shard `opts->shard_rank`
+ * owns. */
+uint64_t rt_shard_pixels(const rt_options *opts);
+
+/* combine_renderbuf's counterpart after an RCCL gather: scatter one shard's
+ * buffers (device) into the full row-major image buffers (device). Either
+ * pair may be NULL. */
+int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, const double *d_shard_rgb, double *d_full_rgb,
+                      const int32_t *d_shard_ids, int32_t *d_full_ids, void *stream);
+
+/* Ray::trace (system.rs:122-133) for a batch of world-space rays (host
+ * arrays, xyz interleaved; directions are used as given).  Ray i draws its
+ * fog random numbers as pixel i, stratum 0, depth 0. */
+int rt_trace_rays(rt_scene *scene, uint64_t seed, uint64_t n, const double *origins, const double *directions,
+                  rt_hit *hits, rt_stats *stats);
+
+/* write_render_result_to_file's pixel math (main.rs:201-222): c = sum /
+ * divisor, sqrt, * 255, min 255, truncate.  The reference passes divisor =
+ * strata + 1.  Host buffers. */
+int rt_tonemap(const double *rgb_sum, uint64_t n_pixels, double divisor, uint8_t *rgb8);
+
+/* Thread-local message for the last non-zero status. */
+const char *rt_last_error(void);
+
+/* ---- host plumbing: scene text -> rt_scene_desc -------------------------- */
+
+/* sdl::parse (sdl.rs:36-38, sdl_grammar.rs).  `base_dir` resolves mesh and
+ * image paths (the reference resolves them against the CWD).  Width/height
+ * feed Camera::new.  The result owns its arrays; free with
+ * rt_scene_desc_free. */
+int rt_sdl_parse(const char *text, const char *base_dir, uint32_t width, uint32_t height, rt_scene_desc **out);
+int rt_sdl_parse_file(const char *path, const char *base_dir, uint32_t width, uint32_t height, rt_scene_desc **out);
+void rt_scene_desc_free(rt_scene_desc *desc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */

@@ -1,0 +1,121 @@
+"""ctypes binding of oracle/liboracle.so — the CPU checker.  Test infrastructure:
+imported only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            build()
+        L = C.CDLL(ORACLE_LIB)
+        dp = C.POINTER(C.c_double)
+        L.oracle_render.restype = C.c_int
+        L.oracle_render.argtypes = [C.POINTER(_capi.rt_scene_desc), C.POINTER(_capi.rt_options), C.c_int, C.c_int, dp,
+                                    C.POINTER(C.c_int32), C.POINTER(_capi.rt_stats)]
+        L.oracle_trace_rays.restype = C.c_int
+        L.oracle_trace_rays.argtypes = [C.POINTER(_capi.rt_scene_desc), C.c_uint64, C.c_uint64, dp, dp,
+                                        C.POINTER(_capi.rt_hit), C.POINTER(_capi.rt_stats)]
+        L.oracle_tonemap.restype = C.c_int
+        L.oracle_tonemap.argtypes = [dp, C.c_uint64, C.c_double, C.POINTER(C.c_uint8)]
+        for name in ("oracle_solve_quadratic", "oracle_solve_cubic", "oracle_solve_quartic"):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = [dp, dp]
+        L.oracle_solve_quartic_f64.restype = C.c_int
+        L.oracle_solve_quartic_f64.argtypes = [C.c_double] * 5 + [dp]
+        L.oracle_matrix_make.restype = None
+        L.oracle_matrix_make.argtypes = [C.c_int, dp, dp]
+        for name in ("oracle_matrix_mul", "oracle_point_mul_matrix", "oracle_direction_mul_matrix"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [dp, dp, dp]
+        for name in ("oracle_matrix_inverse", "oracle_matrix_transpose"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [dp, dp]
+        L.oracle_color_op.restype = None
+        L.oracle_color_op.argtypes = [C.c_int, dp, dp, dp]
+        L.oracle_shape_intervals.restype = C.c_int
+        L.oracle_shape_intervals.argtypes = [C.POINTER(_capi.rt_scene_desc), C.c_int, dp, dp, C.c_int, dp]
+        L.oracle_shape_intersect.restype = C.c_int
+        L.oracle_shape_intersect.argtypes = [C.POINTER(_capi.rt_scene_desc), C.c_int, dp, dp, dp]
+        L.oracle_camera_ray.restype = None
+        L.oracle_camera_ray.argtypes = [C.c_double, C.c_double, C.c_double, dp, dp, C.c_double, C.c_double, dp, dp, dp]
+        L.oracle_philox.restype = None
+        L.oracle_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def arr(*v):
+    return np.ascontiguousarray(np.array(v, dtype=np.float64).ravel())
+
+
+def render(desc_ptr, opts, threads=1, strata_parallel=False, want_ids=True):
+    """-> (rgb_sum [H,W,3] f64, primary_ids [H,W] i32 or None, rt_stats)"""
+    H, W = opts.height, opts.width
+    rgb = np.zeros((H, W, 3), dtype=np.float64)
+    ids = np.full((H, W), -2, dtype=np.int32) if want_ids else None
+    stats = _capi.rt_stats()
+    rc = lib().oracle_render(desc_ptr, C.byref(opts), int(threads), int(bool(strata_parallel)), _dp(rgb),
+                             ids.ctypes.data_as(C.POINTER(C.c_int32)) if want_ids else None, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("oracle_render failed: %d" % rc)
+    return rgb, ids, stats
+
+
+def trace_rays(desc_ptr, origins, directions, seed=1):
+    o = np.ascontiguousarray(origins, dtype=np.float64)
+    d = np.ascontiguousarray(directions, dtype=np.float64)
+    n = o.shape[0]
+    hits = (_capi.rt_hit * n)()
+    stats = _capi.rt_stats()
+    rc = lib().oracle_trace_rays(desc_ptr, seed, n, _dp(o), _dp(d), hits, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("oracle_trace_rays failed: %d" % rc)
+    return hits_to_arrays(hits, n), stats
+
+
+def hits_to_arrays(hits, n):
+    raw = np.frombuffer(hits, dtype=np.dtype([("t", "f8"), ("n", "f8", 3), ("uv", "f8", 2), ("object", "i4"),
+                                              ("pad", "i4")]), count=n)
+    return raw.copy()
+
+
+def tonemap(rgb_sum, divisor):
+    a = np.ascontiguousarray(rgb_sum, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    lib().oracle_tonemap(_dp(a), a.size // 3, float(divisor), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def shape_intervals(desc_ptr, node, o, d, max_intervals=8):
+    out = np.zeros((max_intervals, 2, 6), dtype=np.float64)
+    n = lib().oracle_shape_intervals(desc_ptr, node, _dp(arr(*o)), _dp(arr(*d)), max_intervals, _dp(out))
+    if n < 0:
+        return n, None
+    return n, out[:n]
+
+
+def shape_intersect(desc_ptr, node, o, d):
+    out = np.zeros(6, dtype=np.float64)
+    rc = lib().oracle_shape_intersect(desc_ptr, node, _dp(arr(*o)), _dp(arr(*d)), _dp(out))
+    return rc, out
