@@ -1,0 +1,794 @@
+// rt_dev_shapes.h — per-ray shape evaluation on gfx950.
+//
+// Reference semantics (src/shapes/*.rs) with a different evaluation plan:
+//   * a primitive is visited once, in its own space, through composed maps;
+//   * interval end points are (world t, tag) pairs - the CSG interval algebra of
+//     csg.rs only ever compares t (system.rs:202-206) and negates normals, which
+//     a tag bit records;
+//   * normal and uv are derived afterwards, for the nearest hit only.
+// Situations in which the reference panics are counted and treated as a miss.
+#pragma once
+#include "rt_dev_math.h"
+
+// end-point tag: bits 0-7 leaf (object-relative), 8-10 part, 11 normal negated
+#define TAG_PART_SHIFT 8
+#define TAG_NEG (1u << 11)
+#define PART_CYL_SIDE 0u
+#define PART_CYL_TOP 1u
+#define PART_CYL_BOTTOM 2u
+
+struct Guards {
+    uint32_t g[5];
+    uint32_t overflow;
+};
+
+struct LeafRay {
+    d3 o, d;
+};
+
+RT_DEV LeafRay to_leaf(const DevLeaf &L, d3 ow, d3 dw)
+{
+    LeafRay r;
+    if (L.identity) {
+        r.o = ow;
+        r.d = dw;
+    } else {
+        // Ray::transform (system.rs:145-152)
+        r.o = xf_point(L.W, ow);
+        r.d = normalize3(xf_dir(L.W, dw));
+    }
+    return r;
+}
+
+// Intersection::to_world's t (system.rs:190-195)
+RT_DEV double leaf_t_to_world(const DevLeaf &L, d3 ow, const LeafRay &r, double t)
+{
+    if (L.identity) return t;
+    d3 pw = xf_point(L.O, r.o + r.d * t);
+    return signum(t) * len3(pw - ow);
+}
+
+// plane.rs:9-21
+RT_DEV void dev_plane_uv(d3 n, d3 &u, d3 &v)
+{
+    u = cross3(n, mk3(1.0, 0.0, 0.0));
+    if (len2(u) < 1e-6) u = cross3(n, mk3(0.0, 1.0, 0.0));
+    if (len2(u) < 1e-6) u = cross3(n, mk3(0.0, 0.0, 1.0));
+    u = normalize3(u);
+    v = cross3(n, u);
+}
+
+RT_DEV double axis_of(d3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+RT_DEV d3 axis_vec(int a, double s) { return mk3(a == 0 ? s : 0.0, a == 1 ? s : 0.0, a == 2 ? s : 0.0); }
+
+// ---------------------------------------------------------------------------
+// Leaf-space end points of one primitive.  Returns the number of end points
+// (0, 2 or 4; intervals are consecutive pairs), t[] in leaf space, sub[] =
+// part | TAG_NEG.
+__device__ __noinline__ int torus_ends(const double *p, d3 o, d3 d, double *t, uint32_t *sub, Guards &gd)
+{
+    // torus.rs:52-125
+    double R = p[0], S = p[1];
+    double T = 4.0 * R * R;
+    double G = T * (d.x * d.x + d.y * d.y);
+    double H = 2.0 * T * (o.x * d.x + o.y * d.y);
+    double I = T * (o.x * o.x + o.y * o.y);
+    double J = len2(d);
+    double K = 2.0 * dot3(o, d);
+    double Lc = len2(o) + R * R - S * S;
+    double r[4];
+    int n = dev_solve_quartic_f64(J * J, 2.0 * J * K, 2.0 * J * Lc + K * K - G, 2.0 * K * Lc - H, Lc * Lc - I, r);
+    if (n > 1) {
+        bool nan = false;
+        for (int i = 0; i < 4; ++i)
+            if (i < n && r[i] != r[i]) nan = true;
+        if (nan) {
+            gd.g[4]++;
+            return 0;
+        }
+    }
+    // stable insertion sort
+    for (int i = 1; i < 4; ++i) {
+        if (i >= n) break;
+        double v = r[i];
+        int j = i - 1;
+        while (j >= 0 && r[j] > v) {
+            r[j + 1] = r[j];
+            --j;
+        }
+        r[j + 1] = v;
+    }
+    sub[0] = sub[1] = sub[2] = sub[3] = 0u;
+    if (n == 0) return 0;
+    if (n == 1) {
+        t[0] = t[1] = r[0];
+        return 2;
+    }
+    if (n == 2) {
+        t[0] = r[0];
+        t[1] = r[1];
+        return 2;
+    }
+    if (n == 4) {
+        t[0] = r[0];
+        t[1] = r[1];
+        t[2] = r[2];
+        t[3] = r[3];
+        return 4;
+    }
+    // three roots: pair them by the facing of the surface normal (torus.rs:92-110)
+    int facing[3];
+    for (int k = 0; k < 3; ++k) {
+        d3 q = o + d * r[k];
+        double a = 1.0 - (R / sqrt(q.x * q.x + q.y * q.y));
+        d3 nn = normalize3(mk3(a * q.x, a * q.y, q.z));
+        double s = signum(dot3(nn, d));
+        facing[k] = (s != s) ? 0 : (int)s;
+    }
+    if (facing[0] == -1 && facing[1] == 1 && facing[2] == -1) {
+        t[0] = r[0];
+        t[1] = r[1];
+        t[2] = r[2];
+        t[3] = r[2];
+        return 4;
+    }
+    if (facing[0] == 1 && facing[1] == -1 && facing[2] == 1) {
+        t[0] = r[0];
+        t[1] = r[0];
+        t[2] = r[1];
+        t[3] = r[2];
+        return 4;
+    }
+    gd.g[1]++;
+    return 0;
+}
+
+RT_DEV int leaf_ends(const DevLeaf &L, const LeafRay &ry, double *t, uint32_t *sub, Guards &gd)
+{
+    const d3 o = ry.o, d = ry.d;
+    const double *p = L.p;
+    switch (L.kind) {
+    case DL_SPHERE: {
+        // sphere.rs:41-56,69-90
+        d3 l = o - mk3(p[0], p[1], p[2]);
+        double a = dot3(d, d);
+        double b = 2.0 * dot3(d, l);
+        double c = dot3(l, l) - p[3];
+        double discr = b * b - 4.0 * a * c;
+        if (discr < 0.0) return 0;
+        double t0, t1;
+        if (discr == 0.0) {
+            t0 = t1 = -0.5 * b / a;
+        } else {
+            double sq = sqrt(discr);
+            double q = (b > 0.0) ? -0.5 * (b + sq) : -0.5 * (b - sq);
+            t0 = q / a;
+            t1 = c / q;
+        }
+        if (t0 > t1) {
+            double tmp = t0;
+            t0 = t1;
+            t1 = tmp;
+        }
+        t[0] = t0;
+        t[1] = t1;
+        sub[0] = sub[1] = 0u;
+        return 2;
+    }
+    case DL_PLANE: {
+        // plane.rs:23-32,58-83
+        d3 n = mk3(p[3], p[4], p[5]);
+        double denom = dot3(d, n);
+        if (!(fabs(denom) > 1e-6)) return 0;
+        double tt = dot3(mk3(p[0], p[1], p[2]) - o, n) / denom;
+        t[0] = t[1] = tt;
+        sub[0] = sub[1] = 0u;
+        return 2;
+    }
+    case DL_RECT_XY:
+    case DL_RECT_XZ:
+    case DL_RECT_ZY: {
+        // plane.rs:111-244
+        int axis = L.kind == DL_RECT_XY ? 2 : (L.kind == DL_RECT_XZ ? 1 : 0);
+        double denom = axis_of(d, axis) * p[3];
+        if (!(fabs(denom) > 1e-6)) return 0;
+        double tt = ((axis_of(mk3(p[0], p[1], p[2]), axis) - axis_of(o, axis)) * p[3]) / denom;
+        d3 q = o + d * tt;
+        double c0 = L.kind == DL_RECT_ZY ? q.z : q.x;
+        double c1 = L.kind == DL_RECT_XZ ? q.z : q.y;
+        if (c0 < p[4] || c0 > p[5] || c1 < p[6] || c1 > p[7]) return 0;
+        t[0] = t[1] = tt;
+        sub[0] = sub[1] = 0u;
+        return 2;
+    }
+    case DL_CUBE: {
+        // cube.rs:78-106 over the six rectangles of cube.rs:21-37
+        int nh = 0;
+        double ht[2];
+        uint32_t hf[2];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int axis = f >> 1;
+            const double *fq = p + f * 5;
+            double da = axis_of(d, axis);
+            if (!(fabs(da) > 1e-6)) continue;
+            double tt = (fq[0] - axis_of(o, axis)) / da;
+            d3 q = o + d * tt;
+            double c0 = axis == 0 ? q.z : q.x;
+            double c1 = axis == 1 ? q.z : q.y;
+            if (c0 < fq[1] || c0 > fq[2] || c1 < fq[3] || c1 > fq[4]) continue;
+            if (nh < 2) {
+                ht[nh] = tt;
+                hf[nh] = (uint32_t)f;
+            }
+            ++nh;
+        }
+        if (nh > 2) {
+            gd.g[0]++;
+            return 0;
+        }
+        if (nh == 0) return 0;
+        if (nh == 1) {
+            t[0] = t[1] = ht[0];
+            sub[0] = sub[1] = hf[0] << TAG_PART_SHIFT;
+            return 2;
+        }
+        int first = (ht[0] > ht[1]) ? 1 : 0;
+        t[0] = ht[first];
+        t[1] = ht[1 - first];
+        sub[0] = hf[first] << TAG_PART_SHIFT;
+        sub[1] = (hf[1 - first] << TAG_PART_SHIFT) | TAG_NEG;
+        return 2;
+    }
+    case DL_CYLINDER: {
+        // cylinder.rs:53-144
+        double radius = p[0], height = p[1];
+        double a = d.x * d.x + d.z * d.z;
+        double b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
+        double c = o.x * o.x + o.z * o.z - radius * radius;
+        double discr = b * b - 4.0 * a * c;
+        if (discr < 0.0) return 0;
+        double sq = sqrt(discr);
+        double t0 = (-b + sq) / (2.0 * a);
+        double t1 = (-b - sq) / (2.0 * a);
+        if (t0 > t1) {
+            double tmp = t0;
+            t0 = t1;
+            t1 = tmp;
+        }
+        double y0 = o.y + t0 * d.y;
+        double y1 = o.y + t1 * d.y;
+        double max_y = height / 2.0, min_y = -max_y;
+        bool cap_ok = fabs(d.y) > 1e-6; // the caps are Planes (plane.rs:23-32)
+        double t_top = (max_y - o.y) / d.y;
+        double t_bot = (min_y - o.y) / d.y;
+        const uint32_t SIDE = PART_CYL_SIDE << TAG_PART_SHIFT, TOP = PART_CYL_TOP << TAG_PART_SHIFT,
+                       BOT = PART_CYL_BOTTOM << TAG_PART_SHIFT;
+        if ((y0 < min_y && y1 < min_y) || (y0 > max_y && y1 > max_y)) return 0;
+        bool back_side = (y1 > min_y && y1 < max_y);
+        if (y0 > max_y) {
+            if (!cap_ok) {
+                gd.g[3]++;
+                return 0;
+            }
+            t[0] = t_top;
+            sub[0] = TOP;
+            if (back_side) {
+                t[1] = t1;
+                sub[1] = SIDE;
+            } else {
+                if (!(y1 < min_y)) {
+                    gd.g[3]++;
+                    return 0;
+                }
+                t[1] = t_bot;
+                sub[1] = BOT;
+            }
+            return 2;
+        } else if (y0 < min_y) {
+            if (!cap_ok) {
+                gd.g[3]++;
+                return 0;
+            }
+            t[0] = t_bot;
+            sub[0] = BOT;
+            if (back_side) {
+                t[1] = t1;
+                sub[1] = SIDE;
+            } else {
+                if (!(y1 > max_y)) {
+                    gd.g[3]++;
+                    return 0;
+                }
+                t[1] = t_top;
+                sub[1] = TOP;
+            }
+            return 2;
+        } else {
+            t[0] = t0;
+            sub[0] = SIDE;
+            if (back_side) {
+                t[1] = t1;
+                sub[1] = SIDE;
+            } else if (y1 < min_y) {
+                if (!cap_ok) {
+                    gd.g[3]++;
+                    return 0;
+                }
+                t[1] = t_bot;
+                sub[1] = BOT;
+            } else {
+                if (!(y1 > max_y) || !cap_ok) {
+                    gd.g[3]++;
+                    return 0;
+                }
+                t[1] = t_top;
+                sub[1] = TOP;
+            }
+            return 2;
+        }
+    }
+    case DL_TORUS: return torus_ends(p, o, d, t, sub, gd);
+    default: return 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Normal (leaf space, before the tag's negation) and uv at a leaf-space point.
+RT_DEV void leaf_surface(const DevLeaf &L, const LeafRay &ry, d3 q, uint32_t tag, bool need_uv, d3 &n, double &u, double &v)
+{
+    const double *p = L.p;
+    const uint32_t part = (tag >> TAG_PART_SHIFT) & 7u;
+    u = 0.0;
+    v = 0.0;
+    switch (L.kind) {
+    case DL_SPHERE: {
+        // sphere.rs:27-38
+        n = normalize3(q - mk3(p[0], p[1], p[2]));
+        if (need_uv) {
+            u = (1.0 - atan2(n.z, n.x) / RT_PI) * 0.5;
+            v = acos(n.y) / RT_PI;
+        }
+        break;
+    }
+    case DL_PLANE:
+    case DL_RECT_XY:
+    case DL_RECT_XZ:
+    case DL_RECT_ZY: {
+        // plane.rs:62-79
+        d3 N = L.kind == DL_PLANE ? mk3(p[3], p[4], p[5])
+                                  : axis_vec(L.kind == DL_RECT_XY ? 2 : (L.kind == DL_RECT_XZ ? 1 : 0), p[3]);
+        n = (dot3(ry.d, N) > 0.0) ? N * -1.0 : N;
+        if (need_uv) {
+            d3 bu, bv;
+            dev_plane_uv(n, bu, bv);
+            d3 op = q - mk3(p[0], p[1], p[2]);
+            u = dot3(bu, op);
+            v = dot3(bv, op);
+        }
+        break;
+    }
+    case DL_CUBE: {
+        const int f = (int)part, axis = f >> 1;
+        d3 N = axis_vec(axis, (f & 1) ? 1.0 : -1.0); // min faces carry the reversed normal (cube.rs:29-34)
+        n = (dot3(ry.d, N) > 0.0) ? N * -1.0 : N;
+        if (need_uv) {
+            d3 bu, bv;
+            dev_plane_uv(n, bu, bv);
+            d3 fo = mk3(p[30], p[31], p[32]);
+            if (axis == 0) fo.x = p[f * 5];
+            if (axis == 1) fo.y = p[f * 5];
+            if (axis == 2) fo.z = p[f * 5];
+            d3 op = q - fo;
+            u = dot3(bu, op);
+            v = dot3(bv, op);
+        }
+        break;
+    }
+    case DL_CYLINDER: {
+        double height = p[1], max_y = height / 2.0;
+        if (part == PART_CYL_SIDE) {
+            // cylinder.rs:27-39
+            n = normalize3(mk3(q.x, 0.0, q.z));
+            if (need_uv) {
+                u = (1.0 - atan2(n.z, n.x) / RT_PI) * 0.5;
+                v = 1.0 - (q.y + max_y) / height;
+            }
+        } else {
+            d3 N = mk3(0.0, part == PART_CYL_TOP ? 1.0 : -1.0, 0.0);
+            n = (dot3(ry.d, N) > 0.0) ? N * -1.0 : N;
+            if (need_uv) {
+                d3 bu, bv;
+                dev_plane_uv(n, bu, bv);
+                d3 op = q - mk3(0.0, part == PART_CYL_TOP ? max_y : -max_y, 0.0);
+                u = dot3(bu, op);
+                v = dot3(bv, op);
+            }
+        }
+        break;
+    }
+    case DL_TORUS: {
+        // torus.rs:28-39
+        double a = 1.0 - (p[0] / sqrt(q.x * q.x + q.y * q.y));
+        n = normalize3(mk3(a * q.x, a * q.y, q.z));
+        break;
+    }
+    default: n = mk3(0.0, 0.0, 0.0); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Interval lists: end points (t, tag), 2 per interval.
+struct IvList {
+    double t[2 * DEV_MAX_INTERVALS];
+    uint32_t tag[2 * DEV_MAX_INTERVALS];
+    int n; // intervals
+};
+
+RT_DEV void iv_push(IvList &l, double t0, uint32_t g0, double t1, uint32_t g1, Guards &gd)
+{
+    if (l.n >= DEV_MAX_INTERVALS) {
+        gd.overflow++;
+        return;
+    }
+    l.t[2 * l.n] = t0;
+    l.tag[2 * l.n] = g0;
+    l.t[2 * l.n + 1] = t1;
+    l.tag[2 * l.n + 1] = g1;
+    l.n++;
+}
+
+RT_DEV void iv_copy(IvList &dst, const IvList &src)
+{
+    dst.n = src.n;
+    for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
+        if (i >= 2 * src.n) break;
+        dst.t[i] = src.t[i];
+        dst.tag[i] = src.tag[i];
+    }
+}
+
+// `intervals.sort_by(partial_cmp)`: stable, lexicographic on (entry.t, exit.t).
+// Returns false where the reference would panic on a NaN.
+RT_DEV bool iv_sort(IvList &l)
+{
+    if (l.n > 1) {
+        for (int i = 0; i < 2 * l.n; ++i)
+            if (l.t[i] != l.t[i]) return false;
+    }
+    for (int i = 1; i < l.n; ++i) {
+        double a0 = l.t[2 * i], a1 = l.t[2 * i + 1];
+        uint32_t g0 = l.tag[2 * i], g1 = l.tag[2 * i + 1];
+        int j = i - 1;
+        while (j >= 0 && (l.t[2 * j] > a0 || (l.t[2 * j] == a0 && l.t[2 * j + 1] > a1))) {
+            l.t[2 * j + 2] = l.t[2 * j];
+            l.t[2 * j + 3] = l.t[2 * j + 1];
+            l.tag[2 * j + 2] = l.tag[2 * j];
+            l.tag[2 * j + 3] = l.tag[2 * j + 1];
+            --j;
+        }
+        l.t[2 * j + 2] = a0;
+        l.t[2 * j + 3] = a1;
+        l.tag[2 * j + 2] = g0;
+        l.tag[2 * j + 3] = g1;
+    }
+    return true;
+}
+
+// csg.rs:28-98 / 133-176 / 211-280 on (t, tag) end points.  Returns false on a
+// reference panic.
+__device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B, IvList &out, Guards &gd)
+{
+    out.n = 0;
+    if (op == DEV_OP_UNION) {
+        if (A.n == 0) {
+            iv_copy(out, B);
+            return true;
+        }
+        if (B.n == 0) {
+            iv_copy(out, A);
+            return true;
+        }
+    } else if (op == DEV_OP_INTERSECTION) {
+        if (A.n == 0 || B.n == 0) return true;
+    } else {
+        if (A.n == 0) return true;
+        if (B.n == 0) {
+            iv_copy(out, A);
+            return true;
+        }
+    }
+    int pa = 1, pb = 1;
+    bool ha = true, hb = true;
+    double as = A.t[0], ae = A.t[1], bs = B.t[0], be = B.t[1];
+    uint32_t asg = A.tag[0], aeg = A.tag[1], bsg = B.tag[0], beg = B.tag[1];
+#define NEXT_A()                                                                                                       \
+    do {                                                                                                               \
+        if (pa < A.n) {                                                                                                \
+            as = A.t[2 * pa];                                                                                          \
+            ae = A.t[2 * pa + 1];                                                                                      \
+            asg = A.tag[2 * pa];                                                                                       \
+            aeg = A.tag[2 * pa + 1];                                                                                   \
+            ++pa;                                                                                                      \
+        } else                                                                                                         \
+            ha = false;                                                                                                \
+    } while (0)
+#define NEXT_B()                                                                                                       \
+    do {                                                                                                               \
+        if (pb < B.n) {                                                                                                \
+            bs = B.t[2 * pb];                                                                                          \
+            be = B.t[2 * pb + 1];                                                                                      \
+            bsg = B.tag[2 * pb];                                                                                       \
+            beg = B.tag[2 * pb + 1];                                                                                   \
+            ++pb;                                                                                                      \
+        } else                                                                                                         \
+            hb = false;                                                                                                \
+    } while (0)
+    int guard_iter = 0;
+    while (ha && hb) {
+        if (++guard_iter > 8 * DEV_MAX_INTERVALS) break; // cannot happen; keeps the loop provably finite
+        if (op == DEV_OP_UNION) {
+            if (ae < bs) {
+                iv_push(out, as, asg, ae, aeg, gd);
+                NEXT_A();
+            } else if (be < as) {
+                iv_push(out, bs, bsg, be, beg, gd);
+                NEXT_B();
+            } else {
+                double ns = as, ne = ae;
+                uint32_t nsg = asg, neg = aeg;
+                if (bs < ns) {
+                    ns = bs;
+                    nsg = bsg;
+                }
+                if (be > ne) {
+                    ne = be;
+                    neg = beg;
+                    NEXT_A();
+                    while (ha) {
+                        if (as > ne) break;
+                        ne = ae;
+                        neg = aeg;
+                        NEXT_A();
+                    }
+                }
+                iv_push(out, ns, nsg, ne, neg, gd);
+                NEXT_B();
+            }
+        } else if (op == DEV_OP_INTERSECTION) {
+            if (ae < bs) {
+                NEXT_A();
+            } else if (be < as) {
+                NEXT_B();
+            } else {
+                bool s_from_a = as > bs, e_from_a = ae < be;
+                iv_push(out, s_from_a ? as : bs, s_from_a ? asg : bsg, e_from_a ? ae : be, e_from_a ? aeg : beg, gd);
+                if (be >= ae)
+                    NEXT_A();
+                else
+                    NEXT_B();
+            }
+        } else {
+            if (ae < bs) {
+                iv_push(out, as, asg, ae, aeg, gd);
+                NEXT_A();
+            } else if (be < as) {
+                NEXT_B();
+            } else if (bs <= as && be >= ae) {
+                NEXT_A();
+            } else if (bs <= as && be < ae) {
+                as = be;
+                asg = beg ^ TAG_NEG;
+                NEXT_B();
+            } else if (bs < ae && be < ae) {
+                iv_push(out, as, asg, bs, bsg ^ TAG_NEG, gd);
+                as = be;
+                asg = beg ^ TAG_NEG;
+                NEXT_B();
+            } else if (bs < ae && be >= ae) {
+                iv_push(out, as, asg, bs, bsg ^ TAG_NEG, gd);
+                NEXT_A();
+            } else {
+                gd.g[2]++;
+                return false;
+            }
+        }
+    }
+    if (op == DEV_OP_UNION) {
+        if (ha)
+            iv_push(out, as, asg, ae, aeg, gd);
+        else if (hb)
+            iv_push(out, bs, bsg, be, beg, gd);
+        while (pa < A.n) {
+            iv_push(out, A.t[2 * pa], A.tag[2 * pa], A.t[2 * pa + 1], A.tag[2 * pa + 1], gd);
+            ++pa;
+        }
+        while (pb < B.n) {
+            iv_push(out, B.t[2 * pb], B.tag[2 * pb], B.t[2 * pb + 1], B.tag[2 * pb + 1], gd);
+            ++pb;
+        }
+    } else if (op == DEV_OP_DIFFERENCE) {
+        if (ha) iv_push(out, as, asg, ae, aeg, gd);
+        while (pa < A.n) {
+            iv_push(out, A.t[2 * pa], A.tag[2 * pa], A.t[2 * pa + 1], A.tag[2 * pa + 1], gd);
+            ++pa;
+        }
+    }
+#undef NEXT_A
+#undef NEXT_B
+    if (!iv_sort(out)) {
+        gd.g[4]++;
+        return false;
+    }
+    return true;
+}
+
+// Intervals of one leaf as world-space end points
+RT_DEV void leaf_world_intervals(const DevLeaf &L, uint32_t rel, d3 ow, d3 dw, IvList &out, Guards &gd)
+{
+    LeafRay ry = to_leaf(L, ow, dw);
+    double t[4];
+    uint32_t sub[4];
+    int n = leaf_ends(L, ry, t, sub, gd);
+    out.n = n >> 1;
+    for (int i = 0; i < 4; ++i) {
+        if (i >= n) break;
+        out.t[i] = leaf_t_to_world(L, ow, ry, t[i]);
+        out.tag[i] = sub[i] | rel;
+    }
+}
+
+// Evaluate an object's postfix program; the result is left in `res`.
+__device__ __noinline__ bool csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, IvList &res, Guards &gd)
+{
+    IvList stack[DEV_CSG_STACK];
+    IvList tmp;
+    int sp = 0;
+    for (int pc = 0; pc < ob.prog_len; ++pc) {
+        int word = sc.prog[ob.prog0 + pc];
+        int op = word >> 24;
+        if (op == DEV_OP_LEAF) {
+            if (sp >= DEV_CSG_STACK) {
+                gd.overflow++;
+                return false;
+            }
+            uint32_t rel = (uint32_t)(word & 0xFFFFFF);
+            leaf_world_intervals(sc.leaves[ob.leaf0 + rel], rel, ow, dw, stack[sp], gd);
+            ++sp;
+        } else {
+            if (sp < 2) return false;
+            if (!csg_apply(op, stack[sp - 2], stack[sp - 1], tmp, gd)) return false;
+            iv_copy(stack[sp - 2], tmp);
+            --sp;
+        }
+    }
+    if (sp != 1) return false;
+    iv_copy(res, stack[0]);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Meshes.  mesh.rs:66-113 for one triangle record (v0, v0v1, v0v2).
+RT_DEV bool tri_hit(const double *__restrict__ tr, d3 o, d3 d, double &t, double &u, double &v)
+{
+    d3 v0 = mk3(tr[0], tr[1], tr[2]), e1 = mk3(tr[3], tr[4], tr[5]), e2 = mk3(tr[6], tr[7], tr[8]);
+    d3 pvec = cross3(d, e2);
+    double det = dot3(e1, pvec);
+    if (det < 2.220446049250313e-16) return false; // f64::EPSILON: back faces and edge-on triangles
+    double inv_det = 1.0 / det;
+    d3 tvec = o - v0;
+    u = dot3(tvec, pvec) * inv_det;
+    if (u < 0.0 || u > 1.0) return false;
+    d3 qvec = cross3(tvec, e1);
+    v = dot3(d, qvec) * inv_det;
+    if (v < 0.0 || (u + v) > 1.0) return false;
+    t = dot3(e2, qvec) * inv_det;
+    if (t < 0.0) return false;
+    return true;
+}
+
+// bounding_box.rs:13-44 against the Mesh::new box (which contains the origin)
+RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
+{
+    int sx = inv.x < 0.0, sy = inv.y < 0.0, sz = inv.z < 0.0;
+    double tmin = ((sx ? m.qmax[0] : m.qmin[0]) - o.x) * inv.x;
+    double tmax = ((sx ? m.qmin[0] : m.qmax[0]) - o.x) * inv.x;
+    double tymin = ((sy ? m.qmax[1] : m.qmin[1]) - o.y) * inv.y;
+    double tymax = ((sy ? m.qmin[1] : m.qmax[1]) - o.y) * inv.y;
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    double tzmin = ((sz ? m.qmax[2] : m.qmin[2]) - o.z) * inv.z;
+    double tzmax = ((sz ? m.qmin[2] : m.qmax[2]) - o.z) * inv.z;
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    return true;
+}
+
+// Nearest triangle (smallest t, lowest index on ties) = element 0 of the
+// reference's stable sort over all triangle hits (mesh.rs:54-64).
+__device__ __noinline__ bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 inv, double &best_t,
+                                          uint32_t &best_tri)
+{
+    // clip the ray against the tight (padded) bounds
+    double t0 = 0.0, t1 = 1.0e300;
+    {
+        double lo, hi;
+        lo = (m.bmin[0] - o.x) * inv.x;
+        hi = (m.bmax[0] - o.x) * inv.x;
+        if (lo > hi) { double s = lo; lo = hi; hi = s; }
+        if (lo == lo && lo > t0) t0 = lo;
+        if (hi == hi && hi < t1) t1 = hi;
+        lo = (m.bmin[1] - o.y) * inv.y;
+        hi = (m.bmax[1] - o.y) * inv.y;
+        if (lo > hi) { double s = lo; lo = hi; hi = s; }
+        if (lo == lo && lo > t0) t0 = lo;
+        if (hi == hi && hi < t1) t1 = hi;
+        lo = (m.bmin[2] - o.z) * inv.z;
+        hi = (m.bmax[2] - o.z) * inv.z;
+        if (lo > hi) { double s = lo; lo = hi; hi = s; }
+        if (lo == lo && lo > t0) t0 = lo;
+        if (hi == hi && hi < t1) t1 = hi;
+    }
+    if (t0 > t1) return false;
+    bool found = false;
+    best_t = 1.0e300;
+    best_tri = 0xFFFFFFFFu;
+
+    uint32_t stack_node[DEV_KD_STACK];
+    double stack_tmin[DEV_KD_STACK], stack_tmax[DEV_KD_STACK];
+    int sp = 0;
+    uint32_t node = 0;
+    double tmin = t0, tmax = t1;
+    const DevKdNode *kd = sc.kd + m.kd0;
+    const uint32_t *index = sc.kd_index + m.kd_index0;
+    const double *tris = sc.tris + (size_t)m.tri0 * 9;
+    for (int iter = 0; iter < 4096; ++iter) { // bounded: a tree of depth <= 30 never needs this many steps
+        if (best_t < tmin) break;
+        DevKdNode nd = kd[node];
+        uint32_t axis = nd.a & 3u;
+        if (axis != 3u) {
+            double oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+            double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
+            double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+            double tplane = (nd.split - oa) * ia;
+            bool below_first = (oa < nd.split) || (oa == nd.split && da <= 0.0);
+            uint32_t first = below_first ? node + 1u : (nd.a >> 2);
+            uint32_t second = below_first ? (nd.a >> 2) : node + 1u;
+            // slack: a hit within rounding distance of the plane is searched on both sides
+            double eps = 1e-9 * (fabs(tplane) + 1.0);
+            if (tplane > tmax + eps || tplane <= 0.0) {
+                node = first;
+            } else if (tplane < tmin - eps) {
+                node = second;
+            } else {
+                if (sp < DEV_KD_STACK) {
+                    stack_node[sp] = second;
+                    stack_tmin[sp] = tplane - eps;
+                    stack_tmax[sp] = tmax;
+                    ++sp;
+                }
+                node = first;
+                tmax = tplane + eps;
+            }
+        } else {
+            uint32_t first = nd.a >> 2, cnt = nd.b;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                uint32_t ti = index[first + k];
+                double t, u, v;
+                if (tri_hit(tris + (size_t)ti * 9, o, d, t, u, v)) {
+                    if (t < best_t || (t == best_t && ti < best_tri)) {
+                        best_t = t;
+                        best_tri = ti;
+                        found = true;
+                    }
+                }
+            }
+            if (sp == 0) break;
+            --sp;
+            node = stack_node[sp];
+            tmin = stack_tmin[sp];
+            tmax = stack_tmax[sp];
+        }
+    }
+    return found;
+}

@@ -1,0 +1,541 @@
+// rt_flatten.cpp — rt_scene_desc -> device layout (rt_device.h): composes the
+// per-node transforms along every root-to-primitive path, turns CSG trees into
+// postfix programs, pre-computes the rectangle bounds the reference computes in
+// its constructors, and builds one kd-tree per mesh.
+//
+// The kd-tree is new: the reference tests every triangle of a mesh and sorts
+// the hits (mesh.rs:54-64).  The tree only decides which triangles a ray
+// visits; the triangle test and the "nearest t, lowest index on ties" choice
+// are the reference's, so the result equals the brute-force one.
+#include "rt_flatten.h"
+#include "host_math.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rt_host {
+
+namespace {
+
+struct Err {
+    int status;
+    std::string msg;
+};
+
+void store_xform(const Mat4 &a, DevXform &x)
+{
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 3; ++c) x.m[r * 3 + c] = a.m[r][c];
+}
+
+bool is_affine(const Mat4 &a) { return a.m[0][3] == 0.0 && a.m[1][3] == 0.0 && a.m[2][3] == 0.0 && a.m[3][3] == 1.0; }
+
+bool is_identity(const Mat4 &a)
+{
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            if (a.m[r][c] != ((r == c) ? 1.0 : 0.0)) return false;
+    return true;
+}
+
+bool linear_part_is_identity(const Mat4 &a)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            if (a.m[r][c] != ((r == c) ? 1.0 : 0.0)) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------- kd-tree
+struct Box {
+    double lo[3], hi[3];
+};
+
+struct KdBuilder {
+    const std::vector<Box> &pb;
+    std::vector<DevKdNode> &nodes;
+    std::vector<uint32_t> &index;
+    uint32_t index_base; // start of this mesh's index list
+    int max_depth;
+    static constexpr double kIsect = 20.0, kTrav = 1.0, kEmptyBonus = 0.5;
+
+    void make_leaf(const std::vector<uint32_t> &prims)
+    {
+        DevKdNode n;
+        n.split = 0.0;
+        n.a = (uint32_t)(((index.size() - index_base) << 2) | 3u);
+        n.b = (uint32_t)prims.size();
+        std::vector<uint32_t> sorted = prims;
+        std::sort(sorted.begin(), sorted.end());
+        index.insert(index.end(), sorted.begin(), sorted.end());
+        nodes.push_back(n);
+    }
+
+    void build(const std::vector<uint32_t> &prims, const Box &box, int depth, int bad)
+    {
+        if (prims.size() <= 2 || depth >= max_depth) {
+            make_leaf(prims);
+            return;
+        }
+        double d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
+        double total_sa = 2.0 * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2]);
+        double inv_sa = total_sa > 0.0 ? 1.0 / total_sa : 0.0;
+        double old_cost = kIsect * (double)prims.size();
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1;
+        double best_split = 0.0;
+
+        struct Edge {
+            double t;
+            bool start;
+        };
+        std::vector<Edge> edges(prims.size() * 2);
+        for (int axis = 0; axis < 3; ++axis) {
+            for (size_t i = 0; i < prims.size(); ++i) {
+                edges[2 * i] = Edge{pb[prims[i]].lo[axis], true};
+                edges[2 * i + 1] = Edge{pb[prims[i]].hi[axis], false};
+            }
+            std::sort(edges.begin(), edges.end(), [](const Edge &a, const Edge &b) {
+                if (a.t == b.t) return (int)a.start > (int)b.start;
+                return a.t < b.t;
+            });
+            size_t n_below = 0, n_above = prims.size();
+            int o0 = (axis + 1) % 3, o1 = (axis + 2) % 3;
+            for (size_t i = 0; i < edges.size(); ++i) {
+                if (!edges[i].start) --n_above;
+                double t = edges[i].t;
+                if (t > box.lo[axis] && t < box.hi[axis]) {
+                    double below_sa = 2.0 * (d[o0] * d[o1] + (t - box.lo[axis]) * (d[o0] + d[o1]));
+                    double above_sa = 2.0 * (d[o0] * d[o1] + (box.hi[axis] - t) * (d[o0] + d[o1]));
+                    double eb = (n_above == 0 || n_below == 0) ? kEmptyBonus : 0.0;
+                    double cost = kTrav + kIsect * (1.0 - eb) *
+                                              (below_sa * inv_sa * (double)n_below + above_sa * inv_sa * (double)n_above);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = axis;
+                        best_split = t;
+                    }
+                }
+                if (edges[i].start) ++n_below;
+            }
+        }
+        if (best_cost > old_cost) ++bad;
+        if (best_axis < 0 || (best_cost > 4.0 * old_cost && prims.size() < 16) || bad >= 3) {
+            make_leaf(prims);
+            return;
+        }
+        std::vector<uint32_t> below, above;
+        for (uint32_t p : prims) {
+            // closed on both sides: a triangle touching the plane is listed in both children
+            if (pb[p].lo[best_axis] <= best_split) below.push_back(p);
+            if (pb[p].hi[best_axis] >= best_split) above.push_back(p);
+        }
+        if (below.size() == prims.size() && above.size() == prims.size()) {
+            make_leaf(prims);
+            return;
+        }
+        size_t me = nodes.size();
+        DevKdNode n;
+        n.split = best_split;
+        n.a = (uint32_t)best_axis;
+        n.b = 0;
+        nodes.push_back(n);
+        Box bl = box, bh = box;
+        bl.hi[best_axis] = best_split;
+        bh.lo[best_axis] = best_split;
+        build(below, bl, depth + 1, bad);
+        nodes[me].a = (uint32_t)((nodes.size() << 2) | (uint32_t)best_axis);
+        build(above, bh, depth + 1, bad);
+    }
+};
+
+// ---------------------------------------------------------------- flattening
+struct Flattener {
+    const rt_scene_desc *d;
+    FlatScene &out;
+
+    const rt_shape_node &node(int idx) const
+    {
+        if (idx < 0 || (uint32_t)idx >= d->n_nodes) throw Err{RT_ERR_INVALID, "shape node index out of range"};
+        return d->nodes[idx];
+    }
+
+    void frames(const rt_shape_node &nd, const Mat4 &Wp, const Mat4 &Op, Mat4 &W, Mat4 &O) const
+    {
+        Mat4 w2o = mat_load(nd.w2o), o2w = mat_load(nd.o2w);
+        if (!is_affine(w2o) || !is_affine(o2w))
+            throw Err{RT_ERR_UNSUPPORTED, "projective shape transforms are not supported on the device"};
+        W = mat_mul(Wp, w2o); // world -> parent space -> this node's object space
+        O = mat_mul(o2w, Op);
+    }
+
+    int push_leaf(int kind, const Mat4 &W, const Mat4 &O)
+    {
+        DevLeaf L;
+        std::memset(&L, 0, sizeof(L));
+        L.kind = kind;
+        L.identity = (is_identity(W) && is_identity(O)) ? 1 : 0;
+        store_xform(W, L.W);
+        store_xform(O, L.O);
+        out.leaves.push_back(L);
+        return (int)out.leaves.size() - 1;
+    }
+
+    static void rect_bounds(int kind, const double *p, double *b)
+    {
+        // XYRectangle::new / XZRectangle::new / ZYRectangle::new (plane.rs:119-132,164-177,209-222)
+        double ox = p[0], oy = p[1], oz = p[2], w = p[3], h = p[4];
+        if (kind == RT_SHAPE_XYRECT) {
+            b[0] = ox - w / 2.0;
+            b[1] = ox + w / 2.0;
+            b[2] = oy - h / 2.0;
+            b[3] = oy + h / 2.0;
+        } else if (kind == RT_SHAPE_XZRECT) {
+            b[0] = ox - (w / 2.0);
+            b[1] = ox + w / 2.0;
+            b[2] = oz - (h / 2.0);
+            b[3] = oz + h / 2.0;
+        } else {
+            b[0] = oz - (w / 2.0);
+            b[1] = oz + w / 2.0;
+            b[2] = oy - (h / 2.0);
+            b[3] = oy + h / 2.0;
+        }
+    }
+
+    // a primitive; returns the leaf index
+    int emit_primitive(const rt_shape_node &nd, const Mat4 &W, const Mat4 &O)
+    {
+        const double *p = nd.params;
+        int li = -1;
+        switch (nd.kind) {
+        case RT_SHAPE_SPHERE: {
+            li = push_leaf(DL_SPHERE, W, O);
+            double *q = out.leaves[li].p;
+            q[0] = p[0];
+            q[1] = p[1];
+            q[2] = p[2];
+            q[3] = p[3] * p[3]; // radius.powi(2), sphere.rs:22
+            break;
+        }
+        case RT_SHAPE_PLANE: {
+            li = push_leaf(DL_PLANE, W, O);
+            for (int k = 0; k < 6; ++k) out.leaves[li].p[k] = p[k];
+            break;
+        }
+        case RT_SHAPE_XYRECT:
+        case RT_SHAPE_XZRECT:
+        case RT_SHAPE_ZYRECT: {
+            int kind = nd.kind == RT_SHAPE_XYRECT ? DL_RECT_XY : (nd.kind == RT_SHAPE_XZRECT ? DL_RECT_XZ : DL_RECT_ZY);
+            li = push_leaf(kind, W, O);
+            double *q = out.leaves[li].p;
+            q[0] = p[0];
+            q[1] = p[1];
+            q[2] = p[2];
+            q[3] = (nd.flags & 1) ? -1.0 : 1.0;
+            rect_bounds(nd.kind, p, q + 4);
+            break;
+        }
+        case RT_SHAPE_CUBE: {
+            // Cube::new (cube.rs:21-65): six rectangles built from centre + extent
+            li = push_leaf(DL_CUBE, W, O);
+            double *q = out.leaves[li].p;
+            double mn[3], mx[3];
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = std::fmin(p[k], p[3 + k]);
+                mx[k] = std::fmax(p[k], p[3 + k]);
+            }
+            double c[3], e[3];
+            for (int k = 0; k < 3; ++k) {
+                e[k] = mx[k] - mn[k];
+                c[k] = (mx[k] - mn[k]) / 2.0 + mn[k];
+            }
+            for (int f = 0; f < 6; ++f) {
+                double rp[5];
+                double b[4];
+                double *fq = q + f * 5;
+                if (f < 2) { // zyrect at x: origin (x, cy, cz), width = ez, height = ey
+                    rp[0] = f == 0 ? mn[0] : mx[0];
+                    rp[1] = c[1];
+                    rp[2] = c[2];
+                    rp[3] = e[2];
+                    rp[4] = e[1];
+                    rect_bounds(RT_SHAPE_ZYRECT, rp, b);
+                    fq[0] = rp[0];
+                } else if (f < 4) { // xzrect at y: origin (cx, y, cz), width = ex, height = ez
+                    rp[0] = c[0];
+                    rp[1] = f == 2 ? mn[1] : mx[1];
+                    rp[2] = c[2];
+                    rp[3] = e[0];
+                    rp[4] = e[2];
+                    rect_bounds(RT_SHAPE_XZRECT, rp, b);
+                    fq[0] = rp[1];
+                } else { // xyrect at z: origin (cx, cy, z), width = ex, height = ey
+                    rp[0] = c[0];
+                    rp[1] = c[1];
+                    rp[2] = f == 4 ? mn[2] : mx[2];
+                    rp[3] = e[0];
+                    rp[4] = e[1];
+                    rect_bounds(RT_SHAPE_XYRECT, rp, b);
+                    fq[0] = rp[2];
+                }
+                for (int k = 0; k < 4; ++k) fq[1 + k] = b[k];
+            }
+            q[30] = c[0];
+            q[31] = c[1];
+            q[32] = c[2];
+            break;
+        }
+        case RT_SHAPE_CYLINDER: {
+            li = push_leaf(DL_CYLINDER, W, O);
+            out.leaves[li].p[0] = p[0];
+            out.leaves[li].p[1] = p[1];
+            break;
+        }
+        case RT_SHAPE_TORUS: {
+            li = push_leaf(DL_TORUS, W, O);
+            out.leaves[li].p[0] = p[0];
+            out.leaves[li].p[1] = p[1];
+            break;
+        }
+        default: throw Err{RT_ERR_INVALID, "not a primitive"};
+        }
+        return li;
+    }
+
+    // anything that yields intervals: appends to the program (postfix)
+    void emit_intervals(int idx, const Mat4 &Wp, const Mat4 &Op, int leaf0)
+    {
+        const rt_shape_node &nd = node(idx);
+        if (nd.kind == RT_SHAPE_MEDIUM) {
+            // HomogenousMedium::intersection_intervals forwards the ray untouched
+            // (homogenous_medium.rs:64-66): its own transformation plays no part here.
+            emit_intervals(nd.child_a, Wp, Op, leaf0);
+            return;
+        }
+        Mat4 W, O;
+        frames(nd, Wp, Op, W, O);
+        switch (nd.kind) {
+        case RT_SHAPE_UNION:
+        case RT_SHAPE_INTERSECTION:
+        case RT_SHAPE_DIFFERENCE: {
+            // csg.rs:33-38,216-221 return a child's intervals without this node's
+            // to_world when the sibling list is empty.  With a pure translation that
+            // changes nothing; with any other transform the reference's result is
+            // expressed in the wrong space, which the device does not imitate.
+            if (nd.kind != RT_SHAPE_INTERSECTION && !linear_part_is_identity(mat_load(nd.o2w)))
+                throw Err{RT_ERR_UNSUPPORTED,
+                          "union/difference with a rotating or scaling transform of its own: the reference skips "
+                          "the transform when one operand is missed (csg.rs:33-38,216-221); not reproduced"};
+            emit_intervals(nd.child_a, W, O, leaf0);
+            emit_intervals(nd.child_b, W, O, leaf0);
+            int op = nd.kind == RT_SHAPE_UNION ? DEV_OP_UNION
+                                               : (nd.kind == RT_SHAPE_INTERSECTION ? DEV_OP_INTERSECTION : DEV_OP_DIFFERENCE);
+            out.prog.push_back(op << 24);
+            out.uses_csg = true;
+            break;
+        }
+        case RT_SHAPE_COMPOSITE:
+        case RT_SHAPE_MESH:
+            throw Err{RT_ERR_UNSUPPORTED, "meshes inside CSG or fog boundaries are not supported on the device"};
+        default: {
+            int li = emit_primitive(nd, W, O);
+            int rel = li - leaf0;
+            if (rel >= DEV_MAX_LEAVES_PER_OBJECT) throw Err{RT_ERR_UNSUPPORTED, "too many primitives in one object"};
+            out.prog.push_back((DEV_OP_LEAF << 24) | rel);
+            break;
+        }
+        }
+    }
+
+    void emit_mesh(const rt_shape_node &nd, DevObject &obj)
+    {
+        if (nd.kind != RT_SHAPE_MESH) throw Err{RT_ERR_UNSUPPORTED, "composite children other than meshes"};
+        if (!is_identity(mat_load(nd.o2w)) || !is_identity(mat_load(nd.w2o)))
+            throw Err{RT_ERR_UNSUPPORTED, "mesh with a transformation of its own"};
+        if (nd.child_a < 0 || (uint32_t)nd.child_a >= d->n_meshes) throw Err{RT_ERR_INVALID, "mesh index out of range"};
+        const rt_mesh &m = d->meshes[nd.child_a];
+        DevMesh dm;
+        std::memset(&dm, 0, sizeof(dm));
+        dm.tri0 = (uint32_t)(out.tris.size() / 9);
+        dm.n_tris = m.n_triangles;
+        dm.normal0 = m.first_normal;
+        dm.smooth = (nd.flags & 1) ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) {
+            dm.qmin[k] = dm.qmax[k] = 0.0; // Point::zero() seeds (mesh.rs:32-33)
+            dm.bmin[k] = std::numeric_limits<double>::infinity();
+            dm.bmax[k] = -std::numeric_limits<double>::infinity();
+        }
+        for (uint32_t v = 0; v < m.n_vertices; ++v) {
+            const double *q = d->vertices + 3 * (size_t)(m.first_vertex + v);
+            for (int k = 0; k < 3; ++k) {
+                dm.qmin[k] = std::fmin(dm.qmin[k], q[k]);
+                dm.qmax[k] = std::fmax(dm.qmax[k], q[k]);
+            }
+        }
+        std::vector<Box> pb(m.n_triangles);
+        for (uint32_t t = 0; t < m.n_triangles; ++t) {
+            const uint32_t *tv = d->tri_v + 3 * (size_t)(m.first_triangle + t);
+            const uint32_t *tn = d->tri_n + 3 * (size_t)(m.first_triangle + t);
+            const double *v[3];
+            for (int k = 0; k < 3; ++k) {
+                if (tv[k] >= m.n_vertices || tn[k] >= m.n_normals) throw Err{RT_ERR_INVALID, "triangle index out of range"};
+                v[k] = d->vertices + 3 * (size_t)(m.first_vertex + tv[k]);
+            }
+            for (int k = 0; k < 3; ++k) out.tris.push_back(v[0][k]);
+            for (int k = 0; k < 3; ++k) out.tris.push_back(v[1][k] - v[0][k]); // v0v1 (mesh.rs:74)
+            for (int k = 0; k < 3; ++k) out.tris.push_back(v[2][k] - v[0][k]); // v0v2 (mesh.rs:75)
+            for (int k = 0; k < 3; ++k) out.tri_n.push_back(tn[k]);
+            for (int k = 0; k < 3; ++k) {
+                pb[t].lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k]));
+                pb[t].hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+                dm.bmin[k] = std::fmin(dm.bmin[k], pb[t].lo[k]);
+                dm.bmax[k] = std::fmax(dm.bmax[k], pb[t].hi[k]);
+            }
+        }
+        // pad every box so that rounding in the traversal cannot step over a triangle
+        double ext = 0.0;
+        for (int k = 0; k < 3; ++k)
+            if (m.n_triangles) ext = std::fmax(ext, std::fmax(std::fabs(dm.bmin[k]), std::fabs(dm.bmax[k])));
+        double pad = 1e-9 * (ext > 0.0 ? ext : 1.0);
+        for (auto &b : pb)
+            for (int k = 0; k < 3; ++k) {
+                b.lo[k] -= pad;
+                b.hi[k] += pad;
+            }
+        Box root;
+        for (int k = 0; k < 3; ++k) {
+            if (!m.n_triangles) dm.bmin[k] = dm.bmax[k] = 0.0;
+            dm.bmin[k] -= 2.0 * pad;
+            dm.bmax[k] += 2.0 * pad;
+            root.lo[k] = dm.bmin[k];
+            root.hi[k] = dm.bmax[k];
+        }
+        dm.kd0 = (uint32_t)out.kd.size();
+        dm.kd_index0 = (uint32_t)out.kd_index.size();
+        std::vector<DevKdNode> nodes; // mesh-relative node indices
+        int max_depth = (int)std::lround(8.0 + 1.3 * std::log2((double)std::max<uint32_t>(1u, m.n_triangles)));
+        if (max_depth > DEV_KD_STACK - 2) max_depth = DEV_KD_STACK - 2;
+        KdBuilder kb{pb, nodes, out.kd_index, dm.kd_index0, max_depth};
+        std::vector<uint32_t> all(m.n_triangles);
+        for (uint32_t t = 0; t < m.n_triangles; ++t) all[t] = t;
+        kb.build(all, root, 0, 0);
+        out.kd.insert(out.kd.end(), nodes.begin(), nodes.end());
+        out.meshes.push_back(dm);
+        ++obj.n_meshes;
+    }
+
+    void emit_object(const rt_object &ro)
+    {
+        DevObject obj;
+        std::memset(&obj, 0, sizeof(obj));
+        obj.material = ro.material;
+        obj.leaf0 = (int)out.leaves.size();
+        obj.prog0 = (int)out.prog.size();
+        obj.frame = -1;
+        if (ro.material < 0 || (uint32_t)ro.material >= d->n_materials) throw Err{RT_ERR_INVALID, "material index out of range"};
+        const rt_material &m = d->materials[ro.material];
+        obj.needs_uv = (m.texture >= 0 && d->textures[m.texture].kind != RT_TEX_SOLID) ? 1 : 0;
+
+        const rt_shape_node &root = node(ro.shape);
+        Mat4 I = mat_identity();
+        switch (root.kind) {
+        case RT_SHAPE_COMPOSITE: {
+            obj.kind = DO_MESH;
+            Mat4 W, O;
+            frames(root, I, I, W, O);
+            obj.frame = push_leaf(DL_NONE, W, O);
+            obj.mesh0 = (int)out.meshes.size();
+            for (int k = 0; k < root.child_b; ++k) {
+                int ci = root.child_a + k;
+                if (ci < 0 || (uint32_t)ci >= d->n_child_list) throw Err{RT_ERR_INVALID, "composite child out of range"};
+                emit_mesh(node(d->child_list[ci]), obj);
+            }
+            break;
+        }
+        case RT_SHAPE_MESH: {
+            obj.kind = DO_MESH;
+            obj.frame = push_leaf(DL_NONE, I, I);
+            obj.mesh0 = (int)out.meshes.size();
+            emit_mesh(root, obj);
+            break;
+        }
+        case RT_SHAPE_MEDIUM: {
+            obj.kind = DO_MEDIUM;
+            obj.density = root.params[0];
+            Mat4 W, O;
+            frames(root, I, I, W, O);
+            obj.frame = push_leaf(DL_NONE, W, O);
+            obj.leaf0 = (int)out.leaves.size();
+            emit_intervals(root.child_a, W, O, obj.leaf0);
+            break;
+        }
+        default: {
+            emit_intervals(ro.shape, I, I, obj.leaf0);
+            bool single = (out.prog.size() - (size_t)obj.prog0) == 1;
+            obj.kind = single ? DO_LEAF : DO_CSG;
+            bool entry_mode = root.kind == RT_SHAPE_CUBE || root.kind == RT_SHAPE_PLANE || root.kind == RT_SHAPE_XYRECT ||
+                              root.kind == RT_SHAPE_XZRECT || root.kind == RT_SHAPE_ZYRECT;
+            obj.mode = entry_mode ? DM_FIRST_ENTRY : DM_FIRST_POSITIVE;
+            break;
+        }
+        }
+        obj.n_leaves = (int)out.leaves.size() - obj.leaf0;
+        obj.prog_len = (int)out.prog.size() - obj.prog0;
+        if (obj.kind == DO_MEDIUM && obj.prog_len == 1) obj.prog_len = 0; // single boundary leaf
+        if (obj.kind == DO_LEAF) obj.prog_len = 0;
+        out.objects.push_back(obj);
+    }
+};
+
+} // namespace
+
+int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
+{
+    try {
+        if (!desc) throw Err{RT_ERR_INVALID, "null scene description"};
+        Flattener f{desc, out};
+        for (uint32_t k = 0; k < desc->n_materials; ++k) {
+            const rt_material &m = desc->materials[k];
+            if (m.texture >= (int32_t)desc->n_textures) throw Err{RT_ERR_INVALID, "texture index out of range"};
+            if (m.kind != RT_MAT_DIELECTRIC && m.texture < 0) throw Err{RT_ERR_INVALID, "material without texture"};
+            out.materials.push_back(DevMaterial{m.kind, m.texture, m.fuzz, m.ior, m.intensity});
+        }
+        for (uint32_t k = 0; k < desc->n_textures; ++k) {
+            const rt_texture &t = desc->textures[k];
+            DevTexture o;
+            std::memset(&o, 0, sizeof(o));
+            o.kind = t.kind;
+            for (int c = 0; c < 3; ++c) {
+                o.c1[c] = t.c1[c];
+                o.c2[c] = t.c2[c];
+            }
+            o.scale = t.scale;
+            if (t.kind == RT_TEX_IMAGE) {
+                if (t.image < 0 || (uint32_t)t.image >= desc->n_images) throw Err{RT_ERR_INVALID, "image index out of range"};
+                const rt_image &im = desc->images[t.image];
+                if (im.width == 0 || im.height == 0 ||
+                    im.offset + (uint64_t)im.width * im.height * 3 > desc->n_image_bytes)
+                    throw Err{RT_ERR_INVALID, "image data out of range"};
+                o.width = (int32_t)im.width;
+                o.height = (int32_t)im.height;
+                o.offset = im.offset;
+            }
+            out.textures.push_back(o);
+        }
+        if (desc->n_image_bytes) out.image_data.assign(desc->image_data, desc->image_data + desc->n_image_bytes);
+        if (desc->n_normals) out.normals.assign(desc->normals, desc->normals + 3 * (size_t)desc->n_normals);
+        for (uint32_t k = 0; k < desc->n_objects; ++k) f.emit_object(desc->objects[k]);
+        for (int k = 0; k < 3; ++k) out.background[k] = desc->background[k];
+        out.cam_fov_factor = desc->camera.fov_factor;
+        std::memcpy(out.cam_c2w, desc->camera.camera_to_world, sizeof(out.cam_c2w));
+    } catch (const Err &e) {
+        err = e.msg;
+        return e.status;
+    }
+    return RT_OK;
+}
+
+} // namespace rt_host

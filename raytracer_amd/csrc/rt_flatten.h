@@ -1,0 +1,33 @@
+// rt_flatten.h — host-side result of flattening an rt_scene_desc for the device.
+#pragma once
+#include "../../include/rt_api.h"
+#include "rt_device.h"
+
+#include <string>
+#include <vector>
+
+namespace rt_host {
+
+struct FlatScene {
+    std::vector<DevObject> objects;
+    std::vector<DevLeaf> leaves;
+    std::vector<int32_t> prog;
+    std::vector<DevMesh> meshes;
+    std::vector<DevKdNode> kd;
+    std::vector<uint32_t> kd_index;
+    std::vector<double> tris;
+    std::vector<uint32_t> tri_n;
+    std::vector<double> normals;
+    std::vector<DevMaterial> materials;
+    std::vector<DevTexture> textures;
+    std::vector<uint8_t> image_data;
+    double background[3];
+    double cam_fov_factor;
+    double cam_c2w[16];
+    bool uses_csg = false;
+};
+
+// returns RT_OK or a negative rt_status with `err` filled
+int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err);
+
+} // namespace rt_host

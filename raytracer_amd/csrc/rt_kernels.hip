@@ -1,0 +1,1043 @@
+// rt_kernels.hip — the wavefront path tracer for gfx950 (MI355X) and the
+// device half of the C ABI.
+//
+// One stratum of one shard = one wavefront run:
+//
+//   k_raygen      camera + jitter                        (system.rs:237-242, 57-66)
+//   repeat for depth = 0 .. max_depth-1 while rays remain:
+//     k_intersect nearest hit over the object list        (system.rs:122-133, shapes/*)
+//     k_shade     emit / scatter / terminate, compacting  (system.rs:112-120,135-142,
+//                 survivors into the other ray queue       materials/*, texture.rs)
+//
+// Every path advances one segment per pass, so `depth` is a launch constant.
+// Survivors are appended with one atomic per wave (ballot + popcount prefix),
+// which keeps the queues dense as paths die at different depths.  A path
+// contributes to its pixel exactly once, when it ends:
+//   colour = a_0 * a_1 * ... * a_{k-1} * X,   X = background            (miss, depth cap)
+//                                             X = emit + background     (light)
+// because every reference material either scatters or emits, never both.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_api.h"
+#include "../../include/rt_rng.h"
+#include "rt_dev_shapes.h"
+#include "rt_flatten.h"
+#include "rt_shard.h"
+
+namespace rt_host {
+void set_last_error(const std::string &msg);
+}
+
+// ------------------------------------------------------------------ device buffers
+struct RayQueue {
+    double *o[3];
+    double *d[3];
+    double *thr[3];
+    uint32_t *slot;  // index into the shard's frame buffer
+    uint32_t *pixel; // y * width + x, the random-number key
+};
+
+struct HitBuf {
+    double *t;
+    double *n[3];
+    double *uv[2];
+    int32_t *obj;
+};
+
+struct PassParams {
+    uint64_t seed;
+    uint32_t stratum;
+    uint32_t depth;
+    uint32_t max_depth;
+    uint32_t force_uv;
+    double bias;
+};
+
+#define RT_BLOCK 256
+
+RT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Append with one atomic per wave.  Called by every lane of the wave.
+RT_DEV uint32_t wave_append(bool alive, uint32_t *counter)
+{
+    unsigned long long mask = __ballot(alive);
+    uint32_t base = 0;
+    if (mask != 0ull) {
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+    }
+    return base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+}
+
+// ------------------------------------------------------------------ ray generation
+__global__ void __launch_bounds__(RT_BLOCK) k_raygen(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots,
+                                                      uint32_t s_i, uint32_t s_j, double recip_sqrt_spp, PassParams pp,
+                                                      RayQueue q, uint32_t *count)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
+    for (uint32_t base = wave_first; base < n_slots; base += stride) {
+        uint32_t slot = base + lane_id();
+        uint32_t x = 0, y = 0;
+        bool valid = slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y);
+        uint32_t at = wave_append(valid, count);
+        if (!valid) continue;
+        uint32_t pixel = y * g.width + x;
+        // get_stratified_ray (system.rs:237-242)
+        rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, 0u, RT_RNG_SITE_JITTER, 0u);
+        double sx = (((double)s_i + rt_rng_u0(&blk)) * recip_sqrt_spp) - 0.5;
+        double sy = (((double)s_j + rt_rng_u1(&blk)) * recip_sqrt_spp) - 0.5;
+        double px = (double)x + sx, py = (double)y + sy;
+        // Camera::pixel_ray (system.rs:57-66)
+        double w = (double)g.width, h = (double)g.height;
+        double aspect = w / h;
+        double ndcx = px / w, ndcy = py / h;
+        double cx = (2.0 * ndcx - 1.0) * sc.cam_fov_factor * aspect;
+        double cy = (1.0 - 2.0 * ndcy) * sc.cam_fov_factor;
+        const double *m = sc.cam_c2w;
+        d3 origin = mk3(m[12], m[13], m[14]);
+        d3 dp = mk3(cx * m[0] + cy * m[4] + -1.0 * m[8] + m[12], cx * m[1] + cy * m[5] + -1.0 * m[9] + m[13],
+                    cx * m[2] + cy * m[6] + -1.0 * m[10] + m[14]);
+        d3 dir = normalize3(dp - origin);
+        q.o[0][at] = origin.x;
+        q.o[1][at] = origin.y;
+        q.o[2][at] = origin.z;
+        q.d[0][at] = dir.x;
+        q.d[1][at] = dir.y;
+        q.d[2][at] = dir.z;
+        q.thr[0][at] = 1.0;
+        q.thr[1][at] = 1.0;
+        q.thr[2][at] = 1.0;
+        q.slot[at] = slot;
+        q.pixel[at] = pixel;
+    }
+}
+
+// ------------------------------------------------------------------ nearest hit
+struct Candidate {
+    double t;
+    uint32_t aux;
+    bool ok;
+};
+
+// first_positive_intersection / first_intersection (shapes/mod.rs:45-55) over a list
+RT_DEV Candidate pick_from_list(const IvList &l, int mode)
+{
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    if (l.n == 0) return c;
+    if (mode == DM_FIRST_ENTRY) {
+        c.t = l.t[0];
+        c.aux = l.tag[0];
+        c.ok = true;
+        return c;
+    }
+    for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
+        if (i >= 2 * l.n) break;
+        if (!(l.t[i] < 0.0)) {
+            c.t = l.t[i];
+            c.aux = l.tag[i];
+            c.ok = true;
+            return c;
+        }
+    }
+    return c;
+}
+
+RT_DEV Candidate eval_leaf_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
+{
+    const DevLeaf &L = sc.leaves[ob.leaf0];
+    LeafRay ry = to_leaf(L, o, d);
+    double t[4];
+    uint32_t sub[4];
+    int n = leaf_ends(L, ry, t, sub, gd);
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    int k = -1;
+    if (n > 0) {
+        if (ob.mode == DM_FIRST_ENTRY) {
+            k = 0;
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                if (i >= n) break;
+                if (!(t[i] < 0.0)) {
+                    k = i;
+                    break;
+                }
+            }
+        }
+    }
+    if (k >= 0) {
+        double tk = k == 0 ? t[0] : (k == 1 ? t[1] : (k == 2 ? t[2] : t[3]));
+        uint32_t sk = k == 0 ? sub[0] : (k == 1 ? sub[1] : (k == 2 ? sub[2] : sub[3]));
+        c.t = leaf_t_to_world(L, o, ry, tk);
+        c.aux = sk;
+        c.ok = true;
+    }
+    return c;
+}
+
+__device__ __noinline__ Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
+{
+    IvList res;
+    res.n = 0;
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    if (!csg_eval(sc, ob, o, d, res, gd)) return c;
+    return pick_from_list(res, ob.mode);
+}
+
+// Composite::intersect over Mesh children (composite.rs:20-34, mesh.rs:116-128)
+__device__ __noinline__ Candidate eval_mesh_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d)
+{
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    const DevLeaf &F = sc.leaves[ob.frame];
+    LeafRay ry = to_leaf(F, o, d);
+    d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
+    double best = 0.0;
+    bool found = false;
+    for (int mi = 0; mi < ob.n_meshes; ++mi) {
+        const DevMesh &m = sc.meshes[ob.mesh0 + mi];
+        if (!mesh_box_hit(m, ry.o, inv)) continue;
+        double t;
+        uint32_t tri;
+        if (mesh_nearest(sc, m, ry.o, ry.d, inv, t, tri)) {
+            if (!found || t < best) { // min_by keeps the first minimum
+                best = t;
+                c.aux = ((uint32_t)mi << 24) | (tri & 0xFFFFFFu);
+                found = true;
+            }
+        }
+    }
+    if (found) {
+        c.t = leaf_t_to_world(F, o, ry, best);
+        c.ok = true;
+    }
+    return c;
+}
+
+// HomogenousMedium::intersect (homogenous_medium.rs:29-57)
+__device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
+                                                     d3 d, const PassParams &pp, uint32_t pixel, Guards &gd)
+{
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    const DevLeaf &F = sc.leaves[ob.frame];
+    LeafRay ry = to_leaf(F, o, d);
+    // a world-space distance along the ray is `scale` times longer in the medium's space
+    double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d));
+    IvList res;
+    res.n = 0;
+    if (ob.prog_len == 0) {
+        leaf_world_intervals(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
+    } else if (!csg_eval(sc, ob, o, d, res, gd)) {
+        return c;
+    }
+    if (res.n == 0) return c;
+    int first = 0;
+    while (first < res.n && res.t[2 * first] < 0.0 && res.t[2 * first + 1] < 0.0) ++first; // skip_negative_intervals
+    double dlen = len3(ry.d);
+    uint32_t k = 0;
+    for (int i = first; i < res.n; ++i) {
+        double at = fmax(res.t[2 * i] * scale, 0.0), bt = res.t[2 * i + 1] * scale;
+        double distance = len3(ry.d * (bt - at));
+        rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_MEDIUM + k, obj_index);
+        ++k;
+        double hit_distance = -(1.0 / ob.density) * log(rt_rng_u0(&blk));
+        if (hit_distance < distance) {
+            double tm = at + hit_distance / dlen;
+            c.t = leaf_t_to_world(F, o, ry, tm);
+            c.ok = true;
+            return c;
+        }
+    }
+    return c;
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
+                                                         PassParams pp, int32_t *primary_ids, uint32_t *guards_out)
+{
+    const uint32_t count = *count_ptr;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    Guards gd;
+    for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
+    gd.overflow = 0u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+        uint32_t pixel = q.pixel[i];
+
+        // Ray::trace (system.rs:122-133): first object wins ties, t must be < f64::MAX
+        double best_t = DBL_MAX;
+        int best_obj = -1;
+        uint32_t best_aux = 0u;
+        for (int k = 0; k < sc.n_objects; ++k) {
+            const DevObject &ob = sc.objects[k];
+            Candidate c;
+            switch (ob.kind) {
+            case DO_LEAF: c = eval_leaf_object(sc, ob, o, d, gd); break;
+            case DO_CSG: c = eval_csg_object(sc, ob, o, d, gd); break;
+            case DO_MESH: c = eval_mesh_object(sc, ob, o, d); break;
+            default: c = eval_medium_object(sc, ob, (uint32_t)k, o, d, pp, pixel, gd); break;
+            }
+            // Object::intersect keeps t >= 0 (object.rs:50-54)
+            if (c.ok && c.t >= 0.0 && c.t < DBL_MAX && (best_obj < 0 || c.t < best_t)) {
+                best_t = c.t;
+                best_obj = k;
+                best_aux = c.aux;
+            }
+        }
+
+        d3 n = mk3(0.0, 0.0, 0.0);
+        double u = 0.0, v = 0.0;
+        if (best_obj >= 0) {
+            const DevObject &ob = sc.objects[best_obj];
+            const bool need_uv = ob.needs_uv || pp.force_uv;
+            d3 pw = o + d * best_t;
+            if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
+                const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
+                LeafRay ry = to_leaf(L, o, d);
+                d3 ql = L.identity ? pw : xf_point(L.W, pw);
+                d3 nl;
+                leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
+                n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
+                if (best_aux & TAG_NEG) n = -n;
+            } else if (ob.kind == DO_MESH) {
+                const DevLeaf &F = sc.leaves[ob.frame];
+                const DevMesh &m = sc.meshes[ob.mesh0 + (best_aux >> 24)];
+                LeafRay ry = to_leaf(F, o, d);
+                uint32_t tri = best_aux & 0xFFFFFFu;
+                double tt = 0.0;
+                tri_hit(sc.tris + ((size_t)m.tri0 + tri) * 9, ry.o, ry.d, tt, u, v);
+                const uint32_t *tn = sc.tri_n + ((size_t)m.tri0 + tri) * 3;
+                const double *nb = sc.normals + (size_t)m.normal0 * 3;
+                d3 n0 = mk3(nb[3 * tn[0]], nb[3 * tn[0] + 1], nb[3 * tn[0] + 2]);
+                d3 n1 = mk3(nb[3 * tn[1]], nb[3 * tn[1] + 1], nb[3 * tn[1] + 2]);
+                d3 n2 = mk3(nb[3 * tn[2]], nb[3 * tn[2] + 1], nb[3 * tn[2] + 2]);
+                // mesh.rs:102-106
+                d3 nl = m.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
+                n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
+            } else {
+                const DevLeaf &F = sc.leaves[ob.frame];
+                n = F.identity ? mk3(1.0, 0.0, 0.0) : normalize3(xf_normal(F.W, mk3(1.0, 0.0, 0.0)));
+            }
+        }
+        hit.t[i] = best_obj >= 0 ? best_t : -1.0;
+        hit.n[0][i] = n.x;
+        hit.n[1][i] = n.y;
+        hit.n[2][i] = n.z;
+        hit.uv[0][i] = u;
+        hit.uv[1][i] = v;
+        hit.obj[i] = best_obj;
+        if (primary_ids) primary_ids[q.slot[i]] = best_obj;
+    }
+    for (int k = 0; k < 5; ++k)
+        if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
+    if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
+}
+
+// ------------------------------------------------------------------ shading
+// direction.rs:29-39
+RT_DEV d3 uniform_sphere(const PassParams &pp, uint32_t pixel)
+{
+    rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_SPHERE, 0u);
+    double theta = 2.0 * RT_PI * rt_rng_u0(&blk);
+    double phi = acos(1.0 - 2.0 * rt_rng_u1(&blk));
+    double sp, cp, st, ct;
+    sincos(phi, &sp, &cp);
+    sincos(theta, &st, &ct);
+    return mk3(sp * ct, sp * st, cp);
+}
+
+RT_DEV uint32_t sat_u32(double v)
+{
+    if (!(v > 0.0)) return 0u;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+
+// texture.rs:54-94
+RT_DEV d3 texture_color(const DevScene &sc, int tex, double u, double v)
+{
+    const DevTexture &t = sc.textures[tex];
+    if (t.kind == RT_TEX_SOLID) return mk3(t.c1[0], t.c1[1], t.c1[2]);
+    if (t.kind == RT_TEX_CHECKERBOARD) {
+        double sx = u * t.scale, sy = v * t.scale;
+        double fx = sx - trunc(sx), fy = sy - trunc(sy);
+        bool xp = (fabs(fx) > 0.5) != (fx < 0.0);
+        bool yp = (fabs(fy) > 0.5) != (fy < 0.0);
+        double p = (xp != yp) ? 1.0 : 0.0;
+        return mk3(t.c1[0], t.c1[1], t.c1[2]) * (1.0 - p) + mk3(t.c2[0], t.c2[1], t.c2[2]) * p;
+    }
+    double max_x = (double)(t.width - 1), max_y = (double)(t.height - 1);
+    uint32_t x = sat_u32(u * t.scale * max_x) % (uint32_t)t.width;
+    uint32_t y = sat_u32(v * t.scale * max_y) % (uint32_t)t.height;
+    const uint8_t *c = sc.image_data + t.offset + ((size_t)y * (size_t)t.width + x) * 3;
+    return mk3((double)c[0] / 255.0, (double)c[1] / 255.0, (double)c[2] / 255.0);
+}
+
+RT_DEV double clampd(double lo, double hi, double v) { return fmax(lo, fmin(hi, v)); }
+
+// dielectric.rs:89-108
+RT_DEV double fresnel(d3 inc, d3 nrm, double ior)
+{
+    double cos_i = clampd(-1.0, 1.0, dot3(inc, nrm));
+    double eta_i = 1.0, eta_t = ior;
+    if (cos_i > 0.0) {
+        eta_i = ior;
+        eta_t = 1.0;
+    }
+    double sin_t = eta_i / eta_t * sqrt(fmax(1.0 - cos_i * cos_i, 0.0));
+    if (sin_t >= 1.0) return 1.0;
+    double cos_t = sqrt(fmax(1.0 - sin_t * sin_t, 0.0));
+    cos_i = fabs(cos_i);
+    double r_s = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    double r_p = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_s * r_s + r_p * r_p) / 2.0;
+}
+
+// dielectric.rs:68-86
+RT_DEV d3 refract(d3 inc, d3 nrm, double ior)
+{
+    double cos_i = clampd(-1.0, 1.0, dot3(inc, nrm));
+    double eta_i = 1.0, eta_t = ior;
+    d3 n = nrm;
+    if (cos_i < 0.0) {
+        cos_i = -cos_i;
+    } else {
+        eta_i = ior;
+        eta_t = 1.0;
+        n = -nrm;
+    }
+    double eta = eta_i / eta_t;
+    double k = 1.0 - eta * eta * (1.0 - cos_i * cos_i);
+    if (k < 0.0) return mk3(0.0, 0.0, 0.0);
+    return inc * eta + n * (eta * cos_i - sqrt(k));
+}
+
+RT_DEV d3 reflect3(d3 d, d3 n) { return d - (n * 2.0) * dot3(d, n); } // direction.rs:75-77
+
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
+                                                     RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
+{
+    const uint32_t count = *count_in_ptr;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
+    const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+    for (uint32_t base = wave_first; base < count; base += stride) {
+        const uint32_t i = base + lane_id();
+        const bool active = i < count;
+        bool alive = false;
+        d3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0), thr = mk3(0, 0, 0);
+        uint32_t slot = 0, pixel = 0;
+        if (active) {
+            slot = qin.slot[i];
+            pixel = qin.pixel[i];
+            thr = mk3(qin.thr[0][i], qin.thr[1][i], qin.thr[2][i]);
+            int obj = hit.obj[i];
+            d3 X = bg; // what the path sees where it ends
+            bool ended = true;
+            if (obj >= 0) {
+                d3 o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
+                d3 d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
+                double t = hit.t[i];
+                d3 n = mk3(hit.n[0][i], hit.n[1][i], hit.n[2][i]);
+                double u = hit.uv[0][i], v = hit.uv[1][i];
+                const DevMaterial &m = sc.materials[sc.objects[obj].material];
+                d3 p = o + d * t; // RayHit::point (system.rs:173-175)
+                d3 att = mk3(1.0, 1.0, 1.0);
+                switch (m.kind) {
+                case RT_MAT_LAMBERTIAN: {
+                    // lambertian.rs:20-31
+                    no = p + n * pp.bias;
+                    d3 target = p + n + uniform_sphere(pp, pixel);
+                    nd = normalize3(target - p);
+                    att = texture_color(sc, m.texture, u, v);
+                    ended = false;
+                    break;
+                }
+                case RT_MAT_METAL: {
+                    // metal.rs:21-32
+                    d3 refl = normalize3(reflect3(d, n));
+                    d3 fz = m.fuzz * uniform_sphere(pp, pixel);
+                    no = p + n * pp.bias;
+                    nd = normalize3(refl + fz);
+                    att = texture_color(sc, m.texture, u, v);
+                    ended = false;
+                    break;
+                }
+                case RT_MAT_DIELECTRIC: {
+                    // dielectric.rs:25-53
+                    bool outside = dot3(d, n) < 0.0;
+                    d3 b = n * pp.bias;
+                    double kr = fresnel(d, n, m.ior);
+                    rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_DIELECTRIC, 0u);
+                    d3 fz = m.fuzz * uniform_sphere(pp, pixel);
+                    if (rt_rng_u0(&blk) < kr) {
+                        nd = normalize3(reflect3(d, n) + fz);
+                        no = outside ? p + b : p - b;
+                    } else {
+                        nd = normalize3(refract(d, n, m.ior) + fz);
+                        no = outside ? p - b : p + b;
+                    }
+                    ended = false;
+                    break;
+                }
+                case RT_MAT_DIFFUSE_LIGHT: {
+                    // diffuse_light.rs:19-26 + system.rs:139: emit + background
+                    X = m.intensity * texture_color(sc, m.texture, u, v) + bg;
+                    break;
+                }
+                default: {
+                    // isotropic.rs:19-26
+                    no = p;
+                    nd = uniform_sphere(pp, pixel);
+                    att = texture_color(sc, m.texture, u, v);
+                    ended = false;
+                    break;
+                }
+                }
+                if (!ended) {
+                    thr = mk3(thr.x * att.x, thr.y * att.y, thr.z * att.z);
+                    // the scattered ray has depth + 1; Ray::cast returns the background at max_depth
+                    if (pp.depth + 1u >= pp.max_depth) ended = true;
+                }
+            }
+            if (ended) {
+                double *px = fb + (size_t)slot * 3;
+                px[0] += thr.x * X.x;
+                px[1] += thr.y * X.y;
+                px[2] += thr.z * X.z;
+            } else {
+                alive = true;
+            }
+        }
+        uint32_t at = wave_append(alive, count_out);
+        if (alive) {
+            qout.o[0][at] = no.x;
+            qout.o[1][at] = no.y;
+            qout.o[2][at] = no.z;
+            qout.d[0][at] = nd.x;
+            qout.d[1][at] = nd.y;
+            qout.d[2][at] = nd.z;
+            qout.thr[0][at] = thr.x;
+            qout.thr[1][at] = thr.y;
+            qout.thr[2][at] = thr.z;
+            qout.slot[at] = slot;
+            qout.pixel[at] = pixel;
+        }
+    }
+}
+
+// max_depth == 0: every primary ray returns the background (system.rs:113-114)
+__global__ void k_fill_background(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots, double *fb)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x, y;
+    if (slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y)) {
+        fb[(size_t)slot * 3 + 0] += sc.background[0];
+        fb[(size_t)slot * 3 + 1] += sc.background[1];
+        fb[(size_t)slot * 3 + 2] += sc.background[2];
+    }
+}
+
+__global__ void k_unshard(rt_shard_geom g, uint32_t rank, uint32_t n_slots, const double *shard_rgb, double *full_rgb,
+                          const int32_t *shard_ids, int32_t *full_ids)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x, y;
+    if (slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y)) {
+        size_t p = (size_t)y * g.width + x;
+        if (shard_rgb && full_rgb) {
+            full_rgb[p * 3 + 0] = shard_rgb[(size_t)slot * 3 + 0];
+            full_rgb[p * 3 + 1] = shard_rgb[(size_t)slot * 3 + 1];
+            full_rgb[p * 3 + 2] = shard_rgb[(size_t)slot * 3 + 2];
+        }
+        if (shard_ids && full_ids) full_ids[p] = shard_ids[slot];
+    }
+}
+
+__global__ void k_iota(uint32_t n, uint32_t *slot, uint32_t *pixel, double *t0, double *t1, double *t2)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        slot[i] = i;
+        pixel[i] = i;
+        t0[i] = t1[i] = t2[i] = 1.0;
+    }
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+static bool rt_debug() { static int v = -1; if (v < 0) v = getenv("RT_DEBUG") ? 1 : 0; return v == 1; }
+#define RT_TRACE(...) do { if (rt_debug()) { fprintf(stderr, "[rt] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            rt_host::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                               \
+            return RT_ERR_DEVICE;                                                                                      \
+        }                                                                                                              \
+    } while (0)
+
+struct rt_scene {
+    int device = 0;
+    std::vector<void *> allocs; // scene data
+    DevScene dev;
+    // workspace, grown on demand
+    size_t cap = 0;
+    void *ws = nullptr;
+    RayQueue q[2];
+    HitBuf hit;
+    uint32_t *d_counts = nullptr; // max_depth + 2 counters
+    uint32_t counts_cap = 0;
+    uint32_t *d_guards = nullptr; // 6
+    uint32_t *h_pinned = nullptr; // readback slot
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
+{
+    *out = nullptr;
+    if (v.empty()) return RT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    s->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)p;
+    return RT_OK;
+}
+
+static void free_workspace(rt_scene *s)
+{
+    if (s->ws) (void)hipFree(s->ws);
+    s->ws = nullptr;
+    s->cap = 0;
+}
+
+static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
+{
+    if (cap > s->cap) {
+        free_workspace(s);
+        // 2 queues x (9 f64 + 2 u32) + hits (6 f64 + 1 i32), each array 256-B aligned
+        size_t n = (cap + 63) & ~(size_t)63;
+        size_t bytes = n * (2 * (9 * 8 + 2 * 4) + 6 * 8 + 4);
+        HIP_TRY(hipMalloc(&s->ws, bytes));
+        char *p = (char *)s->ws;
+        auto take = [&](size_t elem) {
+            void *r = p;
+            p += n * elem;
+            return r;
+        };
+        for (int k = 0; k < 2; ++k) {
+            for (int c = 0; c < 3; ++c) s->q[k].o[c] = (double *)take(8);
+            for (int c = 0; c < 3; ++c) s->q[k].d[c] = (double *)take(8);
+            for (int c = 0; c < 3; ++c) s->q[k].thr[c] = (double *)take(8);
+        }
+        s->hit.t = (double *)take(8);
+        for (int c = 0; c < 3; ++c) s->hit.n[c] = (double *)take(8);
+        for (int c = 0; c < 2; ++c) s->hit.uv[c] = (double *)take(8);
+        for (int k = 0; k < 2; ++k) {
+            s->q[k].slot = (uint32_t *)take(4);
+            s->q[k].pixel = (uint32_t *)take(4);
+        }
+        s->hit.obj = (int32_t *)take(4);
+        s->cap = cap;
+    }
+    if (max_depth + 2 > s->counts_cap) {
+        if (s->d_counts) (void)hipFree(s->d_counts);
+        s->d_counts = nullptr;
+        HIP_TRY(hipMalloc((void **)&s->d_counts, (max_depth + 2) * sizeof(uint32_t)));
+        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+        s->h_pinned = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (max_depth + 2 + 8) * sizeof(uint32_t), hipHostMallocDefault));
+        s->counts_cap = max_depth + 2;
+    }
+    if (!s->d_guards) HIP_TRY(hipMalloc((void **)&s->d_guards, 8 * sizeof(uint32_t)));
+    if (!s->ev0) {
+        HIP_TRY(hipEventCreate(&s->ev0));
+        HIP_TRY(hipEventCreate(&s->ev1));
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
+{
+    if (!desc || !out) {
+        rt_host::set_last_error("rt_scene_create: null argument");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    rt_host::FlatScene flat;
+    std::string err;
+    int rc = rt_host::flatten_scene(desc, flat, err);
+    if (rc != RT_OK) {
+        rt_host::set_last_error("rt_scene_create: " + err);
+        return rc;
+    }
+    RT_TRACE("flattened: %zu objects %zu leaves %zu kd nodes", flat.objects.size(), flat.leaves.size(), flat.kd.size());
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        rt_host::set_last_error("rt_scene_create: no HIP device available (this library has no CPU path)");
+        return RT_ERR_DEVICE;
+    }
+    rt_scene *s = new rt_scene();
+    (void)hipGetDevice(&s->device);
+    std::memset(&s->dev, 0, sizeof(s->dev));
+    auto fail = [&](int code) {
+        rt_scene_destroy(s);
+        return code;
+    };
+    if ((rc = upload(s, flat.objects, &s->dev.objects))) return fail(rc);
+    if ((rc = upload(s, flat.leaves, &s->dev.leaves))) return fail(rc);
+    if ((rc = upload(s, flat.prog, &s->dev.prog))) return fail(rc);
+    if ((rc = upload(s, flat.meshes, &s->dev.meshes))) return fail(rc);
+    if ((rc = upload(s, flat.kd, &s->dev.kd))) return fail(rc);
+    if ((rc = upload(s, flat.kd_index, &s->dev.kd_index))) return fail(rc);
+    if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
+    if ((rc = upload(s, flat.tri_n, &s->dev.tri_n))) return fail(rc);
+    if ((rc = upload(s, flat.normals, &s->dev.normals))) return fail(rc);
+    if ((rc = upload(s, flat.materials, &s->dev.materials))) return fail(rc);
+    if ((rc = upload(s, flat.textures, &s->dev.textures))) return fail(rc);
+    if ((rc = upload(s, flat.image_data, &s->dev.image_data))) return fail(rc);
+    s->dev.n_objects = (int32_t)flat.objects.size();
+    for (int k = 0; k < 3; ++k) s->dev.background[k] = flat.background[k];
+    s->dev.cam_fov_factor = flat.cam_fov_factor;
+    std::memcpy(s->dev.cam_c2w, flat.cam_c2w, sizeof(flat.cam_c2w));
+    *out = s;
+    RT_TRACE("scene created");
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return;
+    for (void *p : s->allocs) (void)hipFree(p);
+    free_workspace(s);
+    if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->d_guards) (void)hipFree(s->d_guards);
+    if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+static uint32_t grid_for(uint64_t n)
+{
+    uint64_t b = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (b < 1) b = 1;
+    if (b > 256 * 8) b = 256 * 8; // 256 CUs x 8 blocks, grid-stride beyond that
+    return (uint32_t)b;
+}
+
+static int check_options(const rt_options *o)
+{
+    if (!o || o->width == 0 || o->height == 0 || o->samples == 0) {
+        rt_host::set_last_error("rt_options: width, height and samples must be positive");
+        return RT_ERR_INVALID;
+    }
+    uint32_t sc = o->shard_count ? o->shard_count : 1;
+    if (o->shard_rank >= sc) {
+        rt_host::set_last_error("rt_options: shard_rank out of range");
+        return RT_ERR_INVALID;
+    }
+    if ((uint64_t)o->width * o->height > 0xFFFFFFFFull || o->max_depth > 0xFFFFu) {
+        rt_host::set_last_error("rt_options: image or depth too large for the random-number key");
+        return RT_ERR_INVALID;
+    }
+    return RT_OK;
+}
+
+typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
+
+// the wavefront loop for one shard; d_rgb (sum) and d_ids are in shard layout
+static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int32_t *d_ids, rt_stats *stats,
+                         hipStream_t st, stratum_fn per_stratum, void *user)
+{
+    int rc = check_options(opts);
+    if (rc) return rc;
+    if (!s || !d_rgb) {
+        rt_host::set_last_error("rt_render: null scene or output");
+        return RT_ERR_INVALID;
+    }
+    RT_TRACE("render_strata: device %d", s->device);
+    HIP_TRY(hipSetDevice(s->device));
+    rt_shard_geom g = rt_shard_geom_make(opts->width, opts->height, opts->tile_size, opts->shard_count);
+    const uint32_t rank = opts->shard_rank;
+    const uint64_t n_slots64 = (uint64_t)rt_shard_tiles(&g, rank) * g.tile_px;
+    if (n_slots64 > 0xFFFFFFF0ull) {
+        rt_host::set_last_error("rt_render: shard too large");
+        return RT_ERR_INVALID;
+    }
+    const uint32_t n_slots = (uint32_t)n_slots64;
+    RT_TRACE("slots %u", n_slots);
+    rc = ensure_workspace(s, n_slots ? n_slots : 1, opts->max_depth);
+    if (rc) return rc;
+    RT_TRACE("workspace ok");
+
+    const uint32_t sqrt_spp = (uint32_t)std::sqrt((double)opts->samples); // system.rs:276
+    const double recip = 1.0 / std::sqrt((double)opts->samples);          // system.rs:277
+    const uint32_t strata = sqrt_spp * sqrt_spp;
+
+    rt_stats local;
+    std::memset(&local, 0, sizeof(local));
+    local.strata = strata;
+
+    RT_TRACE("ev0 %p st %p d_rgb %p", (void *)s->ev0, (void *)st, (void *)d_rgb);
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    RT_TRACE("event recorded");
+    HIP_TRY(hipMemsetAsync(d_rgb, 0, (size_t)n_slots * 3 * sizeof(double), st)); // alloc_render_buf
+    if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)n_slots * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_guards, 0, 8 * sizeof(uint32_t), st));
+    RT_TRACE("memsets queued");
+
+    uint32_t done = 0;
+    for (uint32_t s_i = 0; s_i < sqrt_spp && n_slots; ++s_i) {
+        for (uint32_t s_j = 0; s_j < sqrt_spp; ++s_j) {
+            PassParams pp;
+            pp.seed = opts->seed;
+            pp.stratum = s_i * sqrt_spp + s_j;
+            pp.depth = 0;
+            pp.max_depth = opts->max_depth;
+            pp.force_uv = 0;
+            pp.bias = opts->bias;
+            if (opts->max_depth == 0) {
+                hipLaunchKernelGGL(k_fill_background, dim3((n_slots + 255) / 256), dim3(256), 0, st, s->dev, g, rank,
+                                   n_slots, d_rgb);
+            } else {
+                HIP_TRY(hipMemsetAsync(s->d_counts, 0, (opts->max_depth + 2) * sizeof(uint32_t), st));
+                RT_TRACE("launching raygen grid %u", grid_for(n_slots));
+                hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_slots)), dim3(RT_BLOCK), 0, st, s->dev, g, rank, n_slots,
+                                   s_i, s_j, recip, pp, s->q[0], s->d_counts);
+                RT_TRACE("raygen launched");
+                uint32_t live = n_slots; // upper bound until read back
+                int cur = 0;
+                for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
+                    pp.depth = depth;
+                    int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
+                    hipLaunchKernelGGL(k_intersect, dim3(grid_for(live)), dim3(RT_BLOCK), 0, st, s->dev, s->q[cur],
+                                       s->d_counts + depth, s->hit, pp, ids, s->d_guards);
+                    hipLaunchKernelGGL(k_shade, dim3(grid_for(live)), dim3(RT_BLOCK), 0, st, s->dev, s->q[cur],
+                                       s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
+                    local.bounce_passes++;
+                    cur = 1 - cur;
+                    // learn how many paths survived: sizes the next launch and ends the loop
+                    HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts + depth + 1, sizeof(uint32_t),
+                                           hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    live = s->h_pinned[0];
+                    RT_TRACE("depth %u live %u", depth, live);
+                    if (live == 0) break;
+                }
+                HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (opts->max_depth + 1) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                local.primary_rays += s->h_pinned[0];
+                for (uint32_t k = 0; k < opts->max_depth; ++k) local.rays += s->h_pinned[k];
+            }
+            HIP_TRY(hipGetLastError());
+            ++done;
+            if (per_stratum) {
+                int stop = per_stratum(user, done, strata);
+                if (stop < 0) return stop;
+                if (stop > 0) goto finished;
+            }
+        }
+    }
+finished:
+    HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_guards, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
+    local.interval_overflow = s->h_pinned[5];
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    local.ms_device = ms;
+    if (stats) *stats = local;
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,
+                                rt_stats *stats, void *stream)
+{
+    return render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, nullptr, nullptr);
+}
+
+extern "C" int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, const double *d_shard_rgb,
+                                 double *d_full_rgb, const int32_t *d_shard_ids, int32_t *d_full_ids, void *stream)
+{
+    int rc = check_options(opts);
+    if (rc) return rc;
+    rt_shard_geom g = rt_shard_geom_make(opts->width, opts->height, opts->tile_size, opts->shard_count);
+    if (shard_rank >= g.shard_count) {
+        rt_host::set_last_error("rt_unshard_device: shard_rank out of range");
+        return RT_ERR_INVALID;
+    }
+    uint32_t n_slots = rt_shard_tiles(&g, shard_rank) * g.tile_px;
+    if (n_slots == 0) return RT_OK;
+    hipLaunchKernelGGL(k_unshard, dim3((n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, shard_rank, n_slots,
+                       d_shard_rgb, d_full_rgb, d_shard_ids, d_full_ids);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+struct HostRenderCtx {
+    const rt_options *opts;
+    double *d_shard_rgb, *d_full_rgb;
+    double *h_rgb;
+    rt_progress_cb cb;
+    void *user;
+};
+
+static int host_render_stratum(void *u, uint32_t done, uint32_t total)
+{
+    HostRenderCtx *c = (HostRenderCtx *)u;
+    if (!c->cb) return 0;
+    int rc = rt_unshard_device(c->opts, 0, c->d_shard_rgb, c->d_full_rgb, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    size_t n = (size_t)c->opts->width * c->opts->height;
+    if (hipMemcpy(c->h_rgb, c->d_full_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        rt_host::set_last_error("rt_render: copy to host failed");
+        return RT_ERR_DEVICE;
+    }
+    return c->cb(c->user, done, total, c->h_rgb) ? 1 : 0;
+}
+
+extern "C" int rt_render(rt_scene *scene, const rt_options *opts_in, double *rgb_sum, int32_t *primary_ids,
+                         rt_stats *stats, rt_progress_cb cb, void *user)
+{
+    int rc = check_options(opts_in);
+    if (rc) return rc;
+    if (!scene || !rgb_sum) {
+        rt_host::set_last_error("rt_render: null scene or output");
+        return RT_ERR_INVALID;
+    }
+    rt_options opts = *opts_in; // a whole image on this GPU
+    opts.shard_rank = 0;
+    opts.shard_count = 1;
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t n = (size_t)opts.width * opts.height;
+    const size_t n_slots = rt_shard_pixels(&opts);
+    double *d_shard = nullptr, *d_full = nullptr;
+    int32_t *d_ids_shard = nullptr, *d_ids_full = nullptr;
+    auto cleanup = [&]() {
+        if (d_shard) (void)hipFree(d_shard);
+        if (d_full) (void)hipFree(d_full);
+        if (d_ids_shard) (void)hipFree(d_ids_shard);
+        if (d_ids_full) (void)hipFree(d_ids_full);
+    };
+#define TRY_OR_CLEAN(expr)                                                                                             \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            rt_host::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                               \
+            cleanup();                                                                                                 \
+            return RT_ERR_DEVICE;                                                                                      \
+        }                                                                                                              \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void **)&d_shard, n_slots * 3 * sizeof(double)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_full, n * 3 * sizeof(double)));
+    if (primary_ids) {
+        TRY_OR_CLEAN(hipMalloc((void **)&d_ids_shard, n_slots * sizeof(int32_t)));
+        TRY_OR_CLEAN(hipMalloc((void **)&d_ids_full, n * sizeof(int32_t)));
+    }
+    HostRenderCtx ctx{&opts, d_shard, d_full, rgb_sum, cb, user};
+    rc = render_strata(scene, &opts, d_shard, d_ids_shard, stats, nullptr, host_render_stratum, &ctx);
+    if (rc == RT_OK) rc = rt_unshard_device(&opts, 0, d_shard, d_full, d_ids_shard, d_ids_full, nullptr);
+    if (rc == RT_OK) {
+        TRY_OR_CLEAN(hipMemcpy(rgb_sum, d_full, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (primary_ids) TRY_OR_CLEAN(hipMemcpy(primary_ids, d_ids_full, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    return rc;
+#undef TRY_OR_CLEAN
+}
+
+extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const double *origins, const double *directions,
+                             rt_hit *hits, rt_stats *stats)
+{
+    if (!s || !origins || !directions || !hits) {
+        rt_host::set_last_error("rt_trace_rays: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (n == 0) return RT_OK;
+    if (n > 0x7FFFFFFFull) {
+        rt_host::set_last_error("rt_trace_rays: too many rays in one call");
+        return RT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_workspace(s, (size_t)n, 1);
+    if (rc) return rc;
+    // de-interleave on the host into the SoA queue
+    std::vector<double> col(n);
+    for (int c = 0; c < 3; ++c) {
+        for (uint64_t i = 0; i < n; ++i) col[i] = origins[3 * i + c];
+        HIP_TRY(hipMemcpy(s->q[0].o[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        for (uint64_t i = 0; i < n; ++i) col[i] = directions[3 * i + c];
+        HIP_TRY(hipMemcpy(s->q[0].d[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    uint32_t n32 = (uint32_t)n;
+    hipLaunchKernelGGL(k_iota, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, s->q[0].slot, s->q[0].pixel,
+                       s->q[0].thr[0], s->q[0].thr[1], s->q[0].thr[2]);
+    HIP_TRY(hipMemcpy(s->d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_guards, 0, 8 * sizeof(uint32_t)));
+    PassParams pp;
+    pp.seed = seed;
+    pp.stratum = 0;
+    pp.depth = 0;
+    pp.max_depth = 1;
+    pp.force_uv = 1;
+    pp.bias = 0.0;
+    hipLaunchKernelGGL(k_intersect, dim3(grid_for(n)), dim3(RT_BLOCK), 0, nullptr, s->dev, s->q[0], s->d_counts, s->hit,
+                       pp, (int32_t *)nullptr, s->d_guards);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int32_t> obj(n);
+    std::vector<double> cols[6];
+    double *src[6] = {s->hit.t, s->hit.n[0], s->hit.n[1], s->hit.n[2], s->hit.uv[0], s->hit.uv[1]};
+    for (int c = 0; c < 6; ++c) {
+        cols[c].resize(n);
+        HIP_TRY(hipMemcpy(cols[c].data(), src[c], n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemcpy(obj.data(), s->hit.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        hits[i].t = cols[0][i];
+        hits[i].n[0] = cols[1][i];
+        hits[i].n[1] = cols[2][i];
+        hits[i].n[2] = cols[3][i];
+        hits[i].uv[0] = cols[4][i];
+        hits[i].uv[1] = cols[5][i];
+        hits[i].object = obj[i];
+        hits[i].pad = 0;
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        uint32_t g[6];
+        HIP_TRY(hipMemcpy(g, s->d_guards, sizeof(g), hipMemcpyDeviceToHost));
+        stats->rays = n;
+        for (int k = 0; k < 5; ++k) stats->guards[k] = g[k];
+        stats->interval_overflow = g[5];
+    }
+    return RT_OK;
+}

@@ -1,0 +1,150 @@
+"""Render driver: mirror of reference src/system.rs (`Options`, `RenderProgress`,
+`render`) over librt_amd.so, plus the per-GPU entry points used for tile
+sharding across ranks."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+
+
+@dataclass
+class Options:
+    """system.rs:18-26; defaults are main.rs:50-88.  `seed` keys the
+    counter-based random numbers that replace ThreadRng (include/rt_rng.h)."""
+    num_threads: int = 1  # kept for interface parity; the GPU path ignores it
+    width: int = 1024
+    height: int = 768
+    bias: float = 1e-4
+    max_depth: int = 50
+    samples: int = 1
+    seed: int = 1
+    tile_size: int = 64
+
+    def to_c(self, shard_rank=0, shard_count=1):
+        return _capi.rt_options(width=self.width, height=self.height, samples=self.samples, max_depth=self.max_depth,
+                                bias=self.bias, seed=self.seed, tile_size=self.tile_size, shard_rank=shard_rank,
+                                shard_count=shard_count, flags=0)
+
+
+class RenderProgress:
+    """system.rs:223-227.  `renderbuf` is the running SUM over finished strata,
+    float64 [H, W, 3]."""
+
+    def render_started(self, options):
+        pass
+
+    def sample_finished(self, options, renderbuf):
+        pass
+
+    def render_finished(self, options, renderbuf):
+        pass
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib.rt_last_error().decode("utf-8", "replace")))
+
+
+class DeviceScene:
+    """A scene resident on the current HIP device (rt_scene_create)."""
+
+    def __init__(self, scene):
+        from . import lib
+        self._lib = lib
+        self._h = C.c_void_p()
+        _check(lib, lib.rt_scene_create(scene.desc, C.byref(self._h)), "rt_scene_create")
+
+    def close(self):
+        if self._h:
+            self._lib.rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, options, progress=None, want_ids=True):
+        """Whole image on this GPU -> (rgb_sum [H,W,3] f64, ids [H,W] i32 | None, rt_stats)."""
+        o = options.to_c()
+        H, W = options.height, options.width
+        rgb = np.zeros((H, W, 3), dtype=np.float64)
+        ids = np.zeros((H, W), dtype=np.int32) if want_ids else None
+        stats = _capi.rt_stats()
+
+        def _cb(user, done, total, ptr):
+            if progress is not None:
+                buf = np.ctypeslib.as_array(ptr, shape=(H, W, 3))
+                progress.sample_finished(options, buf)
+            return 0
+
+        cb = _capi.rt_progress_cb(_cb)
+        if progress is not None:
+            progress.render_started(options)
+        rc = self._lib.rt_render(self._h, C.byref(o), rgb.ctypes.data_as(C.POINTER(C.c_double)),
+                                 ids.ctypes.data_as(C.POINTER(C.c_int32)) if want_ids else None, C.byref(stats), cb, None)
+        _check(self._lib, rc, "rt_render")
+        if progress is not None:
+            progress.render_finished(options, rgb)
+        return rgb, ids, stats
+
+    def render_shard(self, options, shard_rank, shard_count, d_rgb_ptr, d_ids_ptr=None, stream=None):
+        """One shard of the tiles into caller-owned device buffers (rt_render_device)."""
+        o = options.to_c(shard_rank, shard_count)
+        stats = _capi.rt_stats()
+        rc = self._lib.rt_render_device(self._h, C.byref(o), C.c_void_p(d_rgb_ptr),
+                                        C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(stats),
+                                        C.c_void_p(stream) if stream else None)
+        _check(self._lib, rc, "rt_render_device")
+        return stats
+
+    def trace_rays(self, origins, directions, seed=1):
+        """Ray::trace for a batch of rays -> structured array (t, n, uv, object), rt_stats."""
+        o = np.ascontiguousarray(origins, dtype=np.float64)
+        d = np.ascontiguousarray(directions, dtype=np.float64)
+        n = o.shape[0]
+        hits = (_capi.rt_hit * max(n, 1))()
+        stats = _capi.rt_stats()
+        rc = self._lib.rt_trace_rays(self._h, seed, n, o.ctypes.data_as(C.POINTER(C.c_double)),
+                                     d.ctypes.data_as(C.POINTER(C.c_double)), hits, C.byref(stats))
+        _check(self._lib, rc, "rt_trace_rays")
+        dt = np.dtype([("t", "f8"), ("n", "f8", 3), ("uv", "f8", 2), ("object", "i4"), ("pad", "i4")])
+        return np.frombuffer(hits, dtype=dt, count=n).copy(), stats
+
+
+def shard_pixels(options, shard_rank, shard_count):
+    from . import lib
+    o = options.to_c(shard_rank, shard_count)
+    return int(lib.rt_shard_pixels(C.byref(o)))
+
+
+def unshard(options, shard_rank, shard_count, d_shard_rgb, d_full_rgb, d_shard_ids=None, d_full_ids=None, stream=None):
+    from . import lib
+    o = options.to_c(shard_rank, shard_count)
+    rc = lib.rt_unshard_device(C.byref(o), shard_rank, C.c_void_p(d_shard_rgb), C.c_void_p(d_full_rgb),
+                               C.c_void_p(d_shard_ids) if d_shard_ids else None,
+                               C.c_void_p(d_full_ids) if d_full_ids else None, C.c_void_p(stream) if stream else None)
+    _check(lib, rc, "rt_unshard_device")
+
+
+def render(options, scene, progress=None):
+    """system::render(options, scene, &mut progress) (system.rs:263-307) on one GPU."""
+    dev = DeviceScene(scene)
+    try:
+        return dev.render(options, progress)
+    finally:
+        dev.close()
+
+
+def tonemap(rgb_sum, divisor):
+    """main.rs:201-222; the reference passes divisor = strata + 1 (its Q1 quirk)."""
+    from . import lib
+    a = np.ascontiguousarray(rgb_sum, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    rc = lib.rt_tonemap(a.ctypes.data_as(C.POINTER(C.c_double)), a.size // 3, float(divisor),
+                        out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    _check(lib, rc, "rt_tonemap")
+    return out
