@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (primary + secondary) at 4K on mesh.scene, 1..N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one complete frame of BASELINE.json's headline workload
+(tests/assets/scenes/mesh.scene, 3840x2160, samples=1): every rank renders its
+interleaved 64x64 tiles with the HIP wavefront tracer (scene already resident
+in HBM), rank 0 gathers the finished tiles over RCCL and scatters them into the
+final image.  The frame's seed changes every step, so nothing can be cached.
+value = rays traced by all ranks in the K timed steps / max-over-ranks time.
+
+Extra objects on the JSON line (see DESIGN.md "Measurement"):
+  roofline      dominant kernel k_intersect: algorithmic bytes (132 B per ray:
+                80-B ray record in, 52-B hit record out) / its HIP-event time
+  frame_hbm     SURVEY 8(d)'s whole-frame figure: (264 B/ray + 24 B/pixel-sample) / frame time
+  cpu_baseline  the CPU oracle (a restatement of the reference, `kind: port`) on a
+                bounded sample of the same scene; N=1, rank 0 only
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SAMPLES = 3840, 2160, 1
+SCENE = "mesh"
+BYTES_PER_RAY_INTERSECT = 80 + 52   # ray record read + hit record written
+BYTES_PER_RAY_FRAME = 2 * 80 + 2 * 52
+BYTES_PER_PIXEL_SAMPLE = 24
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(scene, seconds_hint=20.0):
+    """Time the oracle on the host cores: all-cores row-parallel (reported as
+    cpu_baseline) and single-thread = the reference's own threading at samples=1."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import raytracer_amd as rt
+    w, h = WIDTH // 4, HEIGHT // 4
+    o = rt.Options(width=w, height=h, samples=SAMPLES, seed=1)
+    sc = rt.parse_file(o, os.path.join(ROOT, "tests", "assets", "scenes", scene + ".scene"),
+                       os.path.join(ROOT, "tests", "assets"))
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    _, _, st = oracle_lib.render(sc.desc, o.to_c(), threads=cores, want_ids=False)
+    t_all = time.perf_counter() - t0
+    # single thread on a quarter of that sample again (rows scale linearly)
+    o1 = rt.Options(width=w // 2, height=h // 2, samples=SAMPLES, seed=1)
+    sc1 = rt.parse_file(o1, os.path.join(ROOT, "tests", "assets", "scenes", scene + ".scene"),
+                        os.path.join(ROOT, "tests", "assets"))
+    t0 = time.perf_counter()
+    _, _, st1 = oracle_lib.render(sc1.desc, o1.to_c(), threads=1, want_ids=False)
+    t_one = time.perf_counter() - t0
+    return ({"value": st.rays / t_all / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+             "sample": "%s.scene %dx%d samples=%d seed=1, oracle/liboracle.so row-parallel over %d threads, %.1f s"
+                       % (scene, w, h, SAMPLES, cores, t_all)},
+            {"value": st1.rays / t_one / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+             "sample": "%s.scene %dx%d samples=%d seed=1, one thread (the reference parallelises over strata only), %.1f s"
+                       % (scene, w // 2, h // 2, SAMPLES, t_one)})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--samples", type=int, default=SAMPLES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd import system
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    opts = rt.Options(width=args.width, height=args.height, samples=args.samples, seed=1)
+    scene = rt.parse_file(opts, os.path.join(ROOT, "tests", "assets", "scenes", args.scene + ".scene"),
+                          os.path.join(ROOT, "tests", "assets"))
+    dscene = rt.DeviceScene(scene)  # scene upload: outside the timed region
+
+    n_slots = [system.shard_pixels(opts, r, world) for r in range(world)]
+    max_slots = max(n_slots)
+    shard = torch.zeros(max_slots * 3, dtype=torch.float64, device=dev)
+    full = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if rank == 0 else None
+    gathered = [torch.zeros(max_slots * 3, dtype=torch.float64, device=dev) for _ in range(world)] \
+        if (rank == 0 and world > 1) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        opts.seed = 1 + k
+        st = dscene.render_shard(opts, rank, world, shard.data_ptr(), None, stream)
+        if world > 1:
+            dist.gather(shard, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=stream)
+        else:
+            system.unshard(opts, 0, 1, shard.data_ptr(), full.data_ptr(), stream=stream)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    rays = 0
+    ms_int = 0.0
+    n_int = 0
+    ms_shade = 0.0
+    int_rays = 0
+    for k in range(args.steps):
+        st = step(args.warmup + k)
+        rays += st.rays
+        ms_int += st.ms_intersect
+        ms_shade += st.ms_shade
+        n_int += st.n_intersect_launches
+        int_rays += st.rays
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        rays_total = float(tsum[1])
+    else:
+        rays_total = float(rays)
+
+    if rank == 0:
+        value = rays_total / dt / 1e6
+        ms_step = dt / args.steps * 1e3
+        # dominant kernel: k_intersect on this rank
+        ach = (int_rays * BYTES_PER_RAY_INTERSECT) / (ms_int * 1e-3) / 1e9 if ms_int > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("k_intersect_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        frame_bytes = rays_total * BYTES_PER_RAY_FRAME + args.width * args.height * args.samples * BYTES_PER_PIXEL_SAMPLE * args.steps
+        out = {
+            "metric": "Mrays/sec (primary+secondary) at 4K, mesh.scene",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s.scene %dx%d samples=%d max_depth=50, seed=1+step" %
+                                   (args.scene, args.width, args.height, args.samples),
+                       "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_ray": BYTES_PER_RAY_INTERSECT,
+                         "avg_launch_ms": ms_int / n_int if n_int else None, "launches": n_int,
+                         "ms_intersect_per_step": ms_int / args.steps, "ms_shade_per_step": ms_shade / args.steps},
+            "frame_hbm": {"bytes_per_ray": BYTES_PER_RAY_FRAME, "bytes_per_pixel_sample": BYTES_PER_PIXEL_SAMPLE,
+                          "achieved": frame_bytes / dt / 1e9 / world, "unit": "GB/s per GPU",
+                          "frac": frame_bytes / dt / 1e9 / world / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            allc, one = cpu_baseline(args.scene)
+            out["cpu_baseline"] = allc
+            out["cpu_baseline_reference_threading"] = one
+            out["speedup_vs_cpu_all_cores"] = value / allc["value"]
+            out["speedup_vs_cpu_reference_threading"] = value / one["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,12 @@ typedef struct rt_stats {
     uint32_t guards[5];
     uint32_t interval_overflow; /* CSG interval list exceeded device capacity */
     double ms_device;           /* GPU time of the call, HIP events on its stream */
+    /* per-kernel GPU time, HIP events on the same stream, summed over launches */
+    double ms_raygen;
+    double ms_intersect;
+    double ms_shade;
+    uint32_t n_intersect_launches;
+    uint32_t pad;
 } rt_stats;
 
 /* Nearest-hit record, one per ray: RayHit (system.rs:154-171). */

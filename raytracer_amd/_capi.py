@@ -80,7 +80,8 @@ class rt_options(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("strata", C.c_uint32),
                 ("bounce_passes", C.c_uint32), ("guards", C.c_uint32 * 5), ("interval_overflow", C.c_uint32),
-                ("ms_device", C.c_double)]
+                ("ms_device", C.c_double), ("ms_raygen", C.c_double), ("ms_intersect", C.c_double),
+                ("ms_shade", C.c_double), ("n_intersect_launches", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class rt_hit(C.Structure):

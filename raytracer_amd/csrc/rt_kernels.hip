@@ -615,6 +615,7 @@ struct rt_scene {
     uint32_t *d_guards = nullptr; // 6
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr}; // per-kernel timing inside a pass
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -678,6 +679,7 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
     if (!s->ev0) {
         HIP_TRY(hipEventCreate(&s->ev0));
         HIP_TRY(hipEventCreate(&s->ev1));
+        for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreate(&s->evk[k]));
     }
     return RT_OK;
 }
@@ -740,6 +742,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (int k = 0; k < 4; ++k)
+        if (s->evk[k]) (void)hipEventDestroy(s->evk[k]);
     delete s;
 }
 
@@ -828,6 +832,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
             } else {
                 HIP_TRY(hipMemsetAsync(s->d_counts, 0, (opts->max_depth + 2) * sizeof(uint32_t), st));
                 RT_TRACE("launching raygen grid %u", grid_for(n_slots));
+                HIP_TRY(hipEventRecord(s->evk[3], st));
                 hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_slots)), dim3(RT_BLOCK), 0, st, s->dev, g, rank, n_slots,
                                    s_i, s_j, recip, pp, s->q[0], s->d_counts);
                 RT_TRACE("raygen launched");
@@ -836,10 +841,13 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
+                    HIP_TRY(hipEventRecord(s->evk[0], st));
                     hipLaunchKernelGGL(k_intersect, dim3(grid_for(live)), dim3(RT_BLOCK), 0, st, s->dev, s->q[cur],
                                        s->d_counts + depth, s->hit, pp, ids, s->d_guards);
+                    HIP_TRY(hipEventRecord(s->evk[1], st));
                     hipLaunchKernelGGL(k_shade, dim3(grid_for(live)), dim3(RT_BLOCK), 0, st, s->dev, s->q[cur],
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
+                    HIP_TRY(hipEventRecord(s->evk[2], st));
                     local.bounce_passes++;
                     cur = 1 - cur;
                     // learn how many paths survived: sizes the next launch and ends the loop
@@ -848,6 +856,18 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     HIP_TRY(hipStreamSynchronize(st));
                     live = s->h_pinned[0];
                     RT_TRACE("depth %u live %u", depth, live);
+                    {
+                        float ms_k = 0.f;
+                        if (depth == 0) {
+                            HIP_TRY(hipEventElapsedTime(&ms_k, s->evk[3], s->evk[0]));
+                            local.ms_raygen += ms_k;
+                        }
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evk[0], s->evk[1]));
+                        local.ms_intersect += ms_k;
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evk[1], s->evk[2]));
+                        local.ms_shade += ms_k;
+                        local.n_intersect_launches++;
+                    }
                     if (live == 0) break;
                 }
                 HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (opts->max_depth + 1) * sizeof(uint32_t),
