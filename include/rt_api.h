@@ -236,6 +236,10 @@ int rt_render_device(rt_scene *scene, const rt_options *opts, double *d_rgb_sum,
  * owns. */
 uint64_t rt_shard_pixels(const rt_options *opts);
 
+/* Host-side view of the same layout: pixel_index[slot] = y * width + x, or
+ * 0xFFFFFFFF for padding beyond the image edge; rt_shard_pixels(opts) entries. */
+int rt_shard_map(const rt_options *opts, uint32_t *pixel_index);
+
 /* combine_renderbuf's counterpart after an RCCL gather: scatter one shard's
  * buffers (device) into the full row-major image buffers (device). Either
  * pair may be NULL. */

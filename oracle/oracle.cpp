@@ -1907,6 +1907,51 @@ int oracle_render(const rt_scene_desc *desc, const rt_options *opts, int threads
     return RT_OK;
 }
 
+// Rows [y0, y1) of stratum (0,0) of a frame, at the frame's full geometry: lets a
+// test check a band of a 4K or 8K frame without rendering all of it.
+// rgb: (y1-y0)*W*3, ids: (y1-y0)*W or NULL.
+int oracle_render_rows(const rt_scene_desc *desc, const rt_options *opts, uint32_t y0, uint32_t y1, int threads,
+                       double *rgb, int32_t *ids, rt_stats *stats)
+{
+    if (!desc || !opts || !rgb || y0 >= y1 || y1 > opts->height) return RT_ERR_INVALID;
+    std::unique_ptr<Scene> scene;
+    try {
+        scene = build_scene(desc, opts->width, opts->height);
+    } catch (const std::exception &) {
+        return RT_ERR_INVALID;
+    }
+    RenderContext ctx;
+    ctx.options = Options{opts->width, opts->height, opts->bias, (uint16_t)opts->max_depth, opts->samples};
+    ctx.scene = scene.get();
+    ctx.sqrt_spp = (uint32_t)std::sqrt((double)opts->samples);
+    ctx.recip_sqrt_spp = 1.0 / std::sqrt((double)opts->samples);
+    const uint32_t W = opts->width;
+    double *base = rgb - (size_t)y0 * W * 3; // render_rows indexes by absolute row
+    int32_t *ibase = ids ? ids - (size_t)y0 * W : nullptr;
+    Totals totals;
+    if (threads < 1) threads = 1;
+    std::atomic<uint32_t> next_row{y0};
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= y1) break;
+            render_rows(ctx, opts->seed, base, ibase, 0, 0, y, y + 1);
+        }
+        totals.flush();
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays = totals.rays;
+        stats->primary_rays = (uint64_t)(y1 - y0) * W;
+        stats->strata = 1;
+        for (int k = 0; k < 5; ++k) stats->guards[k] = totals.guards[k];
+    }
+    return RT_OK;
+}
+
 // Ray::trace for a batch of rays (ray i: pixel i, stratum 0, depth 0).
 int oracle_trace_rays(const rt_scene_desc *desc, uint64_t seed, uint64_t n, const double *origins,
                       const double *directions, rt_hit *hits, rt_stats *stats)

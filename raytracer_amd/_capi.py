@@ -100,6 +100,7 @@ SIGNATURES = {
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p, C.POINTER(rt_stats),
                                    C.c_void_p]),
     "rt_shard_pixels": (C.c_uint64, [C.POINTER(rt_options)]),
+    "rt_shard_map": (C.c_int, [C.POINTER(rt_options), C.POINTER(C.c_uint32)]),
     "rt_unshard_device": (C.c_int, [C.POINTER(rt_options), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),

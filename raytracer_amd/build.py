@@ -1,7 +1,7 @@
 """Build recipe for librt_amd.so: hipcc, gfx950 only, in-tree.
 
-    python -m raytracer_amd.build            # build if sources are newer than the library
-    python -m raytracer_amd.build --force
+    python raytracer_amd/build.py            # build if sources are newer than the library
+    python raytracer_amd/build.py --force    # (run by path: importing the package needs the library)
 """
 import os
 import subprocess

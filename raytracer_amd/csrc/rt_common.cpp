@@ -23,6 +23,25 @@ extern "C" uint64_t rt_shard_pixels(const rt_options *opts)
     return (uint64_t)rt_shard_tiles(&g, opts->shard_rank) * g.tile_px;
 }
 
+extern "C" int rt_shard_map(const rt_options *opts, uint32_t *pixel_index)
+{
+    if (!opts || !pixel_index || opts->width == 0 || opts->height == 0) {
+        rt_host::set_last_error("rt_shard_map: bad argument");
+        return RT_ERR_INVALID;
+    }
+    rt_shard_geom g = rt_shard_geom_make(opts->width, opts->height, opts->tile_size, opts->shard_count);
+    if (opts->shard_rank >= g.shard_count) {
+        rt_host::set_last_error("rt_shard_map: shard_rank out of range");
+        return RT_ERR_INVALID;
+    }
+    uint64_t n = (uint64_t)rt_shard_tiles(&g, opts->shard_rank) * g.tile_px;
+    for (uint64_t s = 0; s < n; ++s) {
+        uint32_t x, y;
+        pixel_index[s] = rt_shard_decode(&g, opts->shard_rank, (uint32_t)s, &x, &y) ? y * g.width + x : 0xFFFFFFFFu;
+    }
+    return RT_OK;
+}
+
 // main.rs:201-222: (sum / divisor).gamma_2() -> (v * 255).min(255) as u8.
 // `as u8` saturates: negative -> 0, NaN -> 0; f64::min drops a NaN operand, so
 // a NaN channel becomes min(NaN, 255) = 255.

@@ -121,6 +121,42 @@ def shard_pixels(options, shard_rank, shard_count):
     return int(lib.rt_shard_pixels(C.byref(o)))
 
 
+def shard_map(options, shard_rank, shard_count):
+    """pixel index (y * width + x) of every slot of a shard; -1 marks padding."""
+    from . import lib
+    o = options.to_c(shard_rank, shard_count)
+    n = int(lib.rt_shard_pixels(C.byref(o)))
+    m = np.zeros(n, dtype=np.uint32)
+    _check(lib, lib.rt_shard_map(C.byref(o), m.ctypes.data_as(C.POINTER(C.c_uint32))), "rt_shard_map")
+    out = m.astype(np.int64)
+    out[m == 0xFFFFFFFF] = -1
+    return out
+
+
+def gather_frame(options, shard, rank, world, full=None, maps=None):
+    """The one exchange step of a sharded frame: every rank hands its finished tiles
+    (`shard`: torch tensor [n_slots_max * 3], padded to the largest shard) to rank 0,
+    which scatters them into the row-major image `full` [H * W * 3].  RCCL on GPUs
+    (`nccl` backend), gloo in the CPU tests.  Returns `full` on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        bufs = [torch.empty_like(shard) for _ in range(world)] if rank == 0 else None
+        dist.gather(shard, bufs, dst=0)
+    else:
+        bufs = [shard]
+    if rank != 0:
+        return None
+    if full is None:
+        full = torch.zeros(options.height * options.width * 3, dtype=shard.dtype, device=shard.device)
+    img = full.view(-1, 3)
+    for r in range(world):
+        m = maps[r] if maps is not None else torch.from_numpy(shard_map(options, r, world)).to(shard.device)
+        valid = m >= 0
+        img[m[valid]] = bufs[r].view(-1, 3)[: m.numel()][valid]
+    return full
+
+
 def unshard(options, shard_rank, shard_count, d_shard_rgb, d_full_rgb, d_shard_ids=None, d_full_ids=None, stream=None):
     from . import lib
     o = options.to_c(shard_rank, shard_count)

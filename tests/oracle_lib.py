@@ -29,6 +29,9 @@ def lib():
         L.oracle_render.restype = C.c_int
         L.oracle_render.argtypes = [C.POINTER(_capi.rt_scene_desc), C.POINTER(_capi.rt_options), C.c_int, C.c_int, dp,
                                     C.POINTER(C.c_int32), C.POINTER(_capi.rt_stats)]
+        L.oracle_render_rows.restype = C.c_int
+        L.oracle_render_rows.argtypes = [C.POINTER(_capi.rt_scene_desc), C.POINTER(_capi.rt_options), C.c_uint32,
+                                         C.c_uint32, C.c_int, dp, C.POINTER(C.c_int32), C.POINTER(_capi.rt_stats)]
         L.oracle_trace_rays.restype = C.c_int
         L.oracle_trace_rays.argtypes = [C.POINTER(_capi.rt_scene_desc), C.c_uint64, C.c_uint64, dp, dp,
                                         C.POINTER(_capi.rt_hit), C.POINTER(_capi.rt_stats)]
@@ -79,6 +82,19 @@ def render(desc_ptr, opts, threads=1, strata_parallel=False, want_ids=True):
                              ids.ctypes.data_as(C.POINTER(C.c_int32)) if want_ids else None, C.byref(stats))
     if rc != 0:
         raise RuntimeError("oracle_render failed: %d" % rc)
+    return rgb, ids, stats
+
+
+def render_rows(desc_ptr, opts, y0, y1, threads=1):
+    """rows [y0, y1) of stratum 0 at the frame's full geometry -> (rgb [y1-y0, W, 3], ids, stats)"""
+    W = opts.width
+    rgb = np.zeros((y1 - y0, W, 3), dtype=np.float64)
+    ids = np.full((y1 - y0, W), -2, dtype=np.int32)
+    stats = _capi.rt_stats()
+    rc = lib().oracle_render_rows(desc_ptr, C.byref(opts), y0, y1, int(threads), _dp(rgb),
+                                  ids.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("oracle_render_rows failed: %d" % rc)
     return rgb, ids, stats
 
 

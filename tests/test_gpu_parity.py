@@ -1,0 +1,239 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Tolerances (BASELINE.json north_star): primary-ray hit-object ids equal on >= 99.9 % of
+pixels; mean per-channel error of the tone-mapped image <= 1/255.  Both sides draw the
+same counter-based random numbers (include/rt_rng.h), so in practice almost every pixel
+follows the same path and the tests also assert a much tighter diagnostic: >= 99.9 % of
+pixels agree to 1e-9 relative and the traced-ray counts agree to 0.1 %."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import descs
+import oracle_lib
+import parity
+
+pytestmark = pytest.mark.gpu
+
+ID_MATCH_MIN = 0.999        # north_star
+MEAN_ERR_MAX = 1.0          # in units of 1/255, north_star
+CLOSE_MIN = 0.999           # pixels within 1e-9 relative of the oracle (diagnostic, tighter)
+HIT_TOL = 1e-9              # ray-batch hits: t, n, uv
+
+with open(os.path.join(parity.ROOT, "tests", "golden", "reference_unit_vectors.json")) as f:
+    GOLD = json.load(f)
+
+
+def _check(m, st, rst):
+    assert m["id_match"] >= ID_MATCH_MIN, m
+    assert m["mean_err_255"] <= MEAN_ERR_MAX, m
+    assert m["px_close"] >= CLOSE_MIN, m
+    assert abs(int(st.rays) - int(rst.rays)) <= max(2, 1e-3 * rst.rays), (st.rays, rst.rays)
+    assert list(st.guards) == list(rst.guards)
+    assert st.interval_overflow == 0
+
+
+@pytest.mark.parametrize("name", parity.SCENES)
+def test_scene_matches_oracle(rt, name):
+    o = rt.Options(width=200, height=150, samples=4, seed=3)
+    sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert st.strata == 4 and np.isfinite(rgb).all()
+    _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
+
+
+def test_plumbing_config_three_spheres_640x480(rt):
+    """BASELINE configs[0]: three-spheres at 640x480, samples=1, seed 1."""
+    o = rt.Options(width=640, height=480, samples=1, seed=1)
+    sc = rt.parse_file(o, parity.scene_path("three-spheres"), parity.ASSETS)
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    _check(parity.compare(rgb, ids, ref, rids, 1), st, rst)
+
+
+def test_non_square_sample_count_quirk(rt):
+    """samples=5 renders floor(sqrt(5))^2 = 4 strata with recip 1/sqrt(5)."""
+    o = rt.Options(width=96, height=64, samples=5, seed=2)
+    sc = rt.parse_file(o, parity.scene_path("cylinder"), parity.ASSETS)
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=8)
+    assert st.strata == 4 and rst.strata == 4
+    _check(parity.compare(rgb, ids, ref, rids, 4), st, rst)
+
+
+def test_depth_limits(rt):
+    """max_depth 0 -> background everywhere; max_depth 1 -> only lights are visible."""
+    sc_text = open(parity.scene_path("cornell_box")).read().replace("background color black", "background color rgb <0.1, 0.2, 0.3>")
+    for depth in (0, 1, 3):
+        o = rt.Options(width=80, height=60, samples=1, seed=5, max_depth=depth)
+        sc = rt.parse(o, sc_text, parity.ASSETS)
+        rgb, ids, st = rt.render(o, sc)
+        ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=4)
+        assert np.allclose(rgb, ref, rtol=1e-12, atol=0), depth
+        assert st.rays == rst.rays
+        if depth == 0:
+            assert np.allclose(rgb, [0.1, 0.2, 0.3]) and st.rays == 0
+
+
+def test_full_size_band_mesh_4k(rt):
+    """BASELINE configs[2] at its full size: a band of rows of the 4K frame against the oracle."""
+    o = rt.Options(width=3840, height=2160, samples=1, seed=1)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    dev = rt.DeviceScene(sc)
+    rgb, ids, st = dev.render(o)
+    y0, y1 = 1000, 1024
+    ref, rids, rst = oracle_lib.render_rows(sc.desc, o.to_c(), y0, y1, threads=16)
+    m = parity.compare(rgb[y0:y1], ids[y0:y1], ref, rids, 1)
+    assert m["id_match"] >= ID_MATCH_MIN and m["mean_err_255"] <= MEAN_ERR_MAX and m["px_close"] >= CLOSE_MIN, m
+    # size-independent properties of the whole frame
+    assert np.isfinite(rgb).all() and (rgb >= 0).all()
+    assert rgb.max() <= 3.0 + 1e-12           # attenuations <= 1, the only light has intensity 3
+    assert set(np.unique(ids)) <= {-1, 0, 1, 2}
+    assert st.primary_rays == 3840 * 2160 and st.rays >= st.primary_rays
+    # same seed -> bit-identical frame; sharded rendering -> the same pixels
+    rgb2, ids2, st2 = dev.render(o)
+    assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2) and st.rays == st2.rays
+
+
+def test_sharded_render_equals_whole(rt):
+    """Tiles rendered as 3 shards (as 3 GPUs would) reassemble to the single-GPU frame, bit for bit."""
+    import torch
+    from raytracer_amd import system
+    o = rt.Options(width=300, height=200, samples=4, seed=9, tile_size=32)
+    sc = rt.parse_file(o, parity.scene_path("csg"), parity.ASSETS)
+    dev = rt.DeviceScene(sc)
+    whole, wids, wst = dev.render(o)
+    full = torch.zeros(200 * 300 * 3, dtype=torch.float64, device="cuda")
+    fids = torch.full((200 * 300,), -5, dtype=torch.int32, device="cuda")
+    rays = 0
+    for r in range(3):
+        n = system.shard_pixels(o, r, 3)
+        buf = torch.zeros(n * 3, dtype=torch.float64, device="cuda")
+        ibuf = torch.zeros(n, dtype=torch.int32, device="cuda")
+        st = dev.render_shard(o, r, 3, buf.data_ptr(), ibuf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rays += st.rays
+        system.unshard(o, r, 3, buf.data_ptr(), full.data_ptr(), ibuf.data_ptr(), fids.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy().reshape(200, 300, 3), whole)
+    assert np.array_equal(fids.cpu().numpy().reshape(200, 300), wids)
+    assert rays == wst.rays
+    # and the torch-side scatter used after the RCCL gather gives the same image
+    buf = torch.zeros(system.shard_pixels(o, 0, 1) * 3, dtype=torch.float64, device="cuda")
+    dev.render_shard(o, 0, 1, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    img = system.gather_frame(o, buf, 0, 1)
+    assert np.array_equal(img.cpu().numpy().reshape(200, 300, 3), whole)
+
+
+def test_progress_callbacks(rt):
+    """RenderProgress protocol (system.rs:223-227): started once, one call per stratum with
+    the running sum, finished once."""
+    calls = []
+
+    class P(rt.RenderProgress):
+        def render_started(self, options):
+            calls.append(("start", None))
+
+        def sample_finished(self, options, buf):
+            calls.append(("sample", float(buf.sum())))
+
+        def render_finished(self, options, buf):
+            calls.append(("finish", float(buf.sum())))
+
+    o = rt.Options(width=64, height=48, samples=9, seed=1)
+    sc = rt.parse_file(o, parity.scene_path("transformations"), parity.ASSETS)
+    rt.render(o, sc, P())
+    kinds = [c[0] for c in calls]
+    assert kinds == ["start"] + ["sample"] * 9 + ["finish"]
+    sums = [c[1] for c in calls[1:-1]]
+    assert all(b >= a for a, b in zip(sums, sums[1:])) and abs(sums[-1] - calls[-1][1]) < 1e-9
+
+
+def _random_rays(n, seed, center, radius):
+    rng = np.random.default_rng(seed)
+    o = center + rng.normal(size=(n, 3)) * radius
+    t = center + rng.normal(size=(n, 3)) * radius * 0.3
+    d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+@pytest.mark.parametrize("name,center,radius", [("three-spheres", [0, 1.5, -4], 3.0), ("csg", [0, 1, 0], 3.0),
+                                                ("torus", [0, 1.1, 0], 2.0), ("cylinder", [0, 0.7, 0], 2.5),
+                                                ("mesh", [0, 1, 0], 3.0), ("room", [0, 3, 0], 4.0),
+                                                ("fog_light", [0, 2, -4], 3.0), ("cornell_box", [278, 273, 200], 250.0)])
+def test_ray_batches_match_oracle(rt, name, center, radius):
+    """Ray::trace on arbitrary rays, including rays that start inside shapes and rays with t < 0 roots."""
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+    ro, rd = _random_rays(20000, 11, np.array(center, dtype=float), radius)
+    dev = rt.DeviceScene(sc)
+    got, gst = dev.trace_rays(ro, rd, seed=4)
+    ref, rst = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    same_obj = got["object"] == ref["object"]
+    # Coincident surfaces (the cylinder's cap and the cube's base lie in the floor plane and are
+    # seen by rays from below it): two objects at the same t, and the winner hangs on the last
+    # bit of t.  Such a ray counts as agreeing when both sides hit something at the same distance.
+    tie = (~same_obj) & (got["object"] >= 0) & (ref["object"] >= 0) & \
+        (np.abs(got["t"] - ref["t"]) <= HIT_TOL * np.maximum(1.0, np.abs(ref["t"])))
+    assert (same_obj | tie).mean() >= ID_MATCH_MIN, (same_obj.mean(), tie.mean())
+    hit = same_obj & (ref["object"] >= 0)
+    scale = np.maximum(1.0, np.abs(ref["t"][hit]))
+    assert np.mean(np.abs(got["t"][hit] - ref["t"][hit]) / scale < HIT_TOL) >= ID_MATCH_MIN
+    assert np.mean(np.all(np.abs(got["n"][hit] - ref["n"][hit]) < 1e-7, axis=1)) >= ID_MATCH_MIN
+    assert np.mean(np.all(np.abs(got["uv"][hit] - ref["uv"][hit]) < 1e-6, axis=1)) >= 0.995  # atan2 seams
+    assert list(gst.guards) == list(rst.guards)
+
+
+def test_reference_known_answers_on_device(rt):
+    """The reference's own unit-test vectors, first hit through rt_trace_rays."""
+    for case in GOLD["shape_intervals"]:
+        d = descs.Desc([case["shape"]])
+        dev = rt.DeviceScene(descs.FakeScene(d))
+        got, _ = dev.trace_rays(np.array([case["o"]], dtype=float), np.array([case["d"]], dtype=float))
+        ts, ns = case["t"], case["n"]
+        if case["shape"]["kind"] == "cube":
+            k = 0  # first_intersection: the entry, dropped by Object::intersect when negative
+            expect_hit = ts[0] >= 0
+        else:
+            pos = [i for i, t in enumerate(ts) if not (t < 0)]
+            expect_hit = bool(pos)
+            k = pos[0] if pos else 0
+        if ts[k] == 0.0 or abs(ts[k]) < 1e-9:
+            continue  # t = 0 within rounding: the sign, and with it the hit, is not pinned
+        assert (got["object"][0] >= 0) == expect_hit, case
+        if expect_hit:
+            assert abs(got["t"][0] - ts[k]) < 1e-6 and np.allclose(got["n"][0], ns[k], atol=1e-6), case
+    for case in GOLD["plane_intersect"]:
+        d = descs.Desc([{"kind": "plane", "params": case["origin"] + case["normal"]}])
+        dev = rt.DeviceScene(descs.FakeScene(d))
+        got, _ = dev.trace_rays(np.array([case["o"]], dtype=float), np.array([case["d"]], dtype=float))
+        expect = case["hit"] and case["t"] >= 0
+        assert (got["object"][0] >= 0) == expect
+        if expect:
+            assert abs(got["t"][0] - case["t"]) < 1e-6 and np.allclose(got["n"][0], case["n"], atol=1e-6)
+
+
+def test_edge_cases(rt):
+    """Empty batch, a 1x1 image, an image smaller than a tile, axis-parallel rays."""
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse_file(o, parity.scene_path("cylinder"), parity.ASSETS)
+    dev = rt.DeviceScene(sc)
+    got, _ = dev.trace_rays(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert len(got) == 0
+    for w, h in ((1, 1), (5, 3), (65, 9)):
+        oo = rt.Options(width=w, height=h, samples=1, seed=1)
+        s2 = rt.parse_file(oo, parity.scene_path("cylinder"), parity.ASSETS)
+        rgb, ids, st = rt.render(oo, s2)
+        ref, rids, rst = oracle_lib.render(s2.desc, oo.to_c(), threads=1)
+        assert np.array_equal(ids, rids) and np.allclose(rgb, ref, rtol=1e-9, atol=1e-12)
+    # vertical rays make the cylinder's quadratic degenerate (a = 0): the reference panics
+    # (cylinder.rs:136); both sides count the guard and treat the object as missed
+    ro = np.array([[-0.5, 5.0, 0.0], [0.3, 5.0, 0.2]])
+    rd = np.array([[0.0, -1.0, 0.0], [0.0, -1.0, 0.0]])
+    got, gst = dev.trace_rays(ro, rd)
+    ref, rst = oracle_lib.trace_rays(sc.desc, ro, rd)
+    assert list(got["object"]) == list(ref["object"]) and list(gst.guards) == list(rst.guards)

@@ -1,0 +1,193 @@
+"""Host-side logic of the product that needs no GPU: the C ABI surface, the scene
+parser (sdl_grammar.rs restated), the OBJ loader, shard geometry, tone mapping."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import parity
+from raytracer_amd import _capi
+
+ROOT = parity.ROOT
+
+
+def test_library_exports_every_declared_symbol(rt):
+    """Every function include/rt_api.h declares is exported by librt_amd.so and bound in _capi."""
+    with open(os.path.join(ROOT, "include", "rt_api.h")) as f:
+        text = f.read()
+    declared = set(re.findall(r"^\s*(?:const\s+)?[a-z_0-9]+\s*\*?\s*(rt_[a-z_0-9]+)\s*\(", text, re.M))
+    declared -= {"rt_progress_cb"}
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    for name in declared:
+        assert getattr(rt.lib, name) is not None
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_capi.rt_options) == 48
+    assert C.sizeof(_capi.rt_shape_node) == 16 + 8 * 8 + 2 * 128
+    assert C.sizeof(_capi.rt_hit) == 56
+    assert C.sizeof(_capi.rt_stats) == 88
+
+
+# objects per scene, in file order
+EXPECTED_OBJECTS = {"three-spheres": 11, "cornell_box": 8, "mesh": 3, "torus": 3, "csg": 3, "cylinder": 4,
+                    "transformations": 3, "room": 5, "fog_light": 5}
+
+
+@pytest.mark.parametrize("name", parity.SCENES)
+def test_parse_shipped_scenes(rt, name):
+    o = rt.Options(width=64, height=48)
+    sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+    assert sc.n_objects == EXPECTED_OBJECTS[name]
+    d = sc.desc.contents
+    for k in range(d.n_objects):
+        assert 0 <= d.objects[k].shape < d.n_nodes and 0 <= d.objects[k].material < d.n_materials
+
+
+def test_complex_scene_is_rejected_like_the_reference(rt):
+    """scenes/complex.scene uses an obsolete dialect (`location`, ...): sdl_grammar.rs:37-40 cannot parse it."""
+    o = rt.Options(width=64, height=48)
+    with pytest.raises(rt.sdl.ParseError):
+        rt.parse_file(o, parity.scene_path("complex"), parity.ASSETS)
+
+
+def test_mesh_scene_contents(rt):
+    o = rt.Options(width=64, height=48)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)  # keep the owner alive
+    d = sc.desc.contents
+    assert d.n_triangles == 2304 and d.n_vertices == 1152 and d.n_normals == 1054 and d.n_meshes == 1
+    tv = np.ctypeslib.as_array(d.tri_v, shape=(2304 * 3,))
+    assert tv.min() == 0 and tv.max() == 1151
+    # first face `f 1//1 13//2 14//3 2//4` fans into (0,12,13) and (0,13,1)
+    assert list(tv[:6]) == [0, 12, 13, 0, 13, 1]
+    root = d.nodes[d.objects[2].shape]
+    assert root.kind == _capi.RT_SHAPE_COMPOSITE and root.child_b == 1
+    assert root.o2w[13] == 1.0  # translate <0, 1, 0>
+
+
+def test_monkey_obj_triangulation(rt, tmp_path):
+    scene = 'camera { origin <0,0,5> look_at <0,0,0> }\nobject { mesh { file "Monkey.obj" } material { lambertian texture { solid color white } } }\n'
+    sc = rt.parse(rt.Options(width=8, height=8), scene, parity.ASSETS)
+    d = sc.desc.contents
+    assert d.n_triangles == 468 * 2 + 32 and d.n_vertices == 507
+
+
+def test_camera_and_defaults(rt):
+    o = rt.Options(width=640, height=480)
+    sc = rt.parse_file(o, parity.scene_path("cornell_box"), parity.ASSETS)
+    d = sc.desc.contents
+    assert abs(d.camera.fov_factor - np.tan(np.radians(20.0))) < 1e-15  # fov 40
+    assert list(d.camera.camera_to_world)[12:15] == [278.0, 273.0, -800.0]
+    sc2 = rt.parse_file(o, parity.scene_path("torus"), parity.ASSETS)
+    d2 = sc2.desc.contents
+    assert abs(d2.camera.fov_factor - np.tan(np.radians(30.0))) < 1e-15  # default fov 60 (sdl_grammar.rs:39)
+    assert tuple(d2.background) == (0.0, 0.0, 0.0)
+
+
+CAM = "camera { origin <0,0,5> look_at <0,0,0> }\n"
+MAT = " material { lambertian texture { solid color white } } "
+
+
+def test_grammar_details(rt):
+    o = rt.Options(width=8, height=8)
+    # short vectors, named directions, colour spelling, comments, negative and exponent floats
+    text = ("options { background colour rgb <0.25> }\n" + CAM +
+            "// c\nobject \"a\" { /* b */ plane { origin <1> normal up }" + MAT + "}\n"
+            "object { sphere { origin <-1.5, 2.0e1, 3> radius 2 transform { scale <2> rotate_y 90 translate left } }" + MAT + "}\n")
+    sc = rt.parse(o, text, ".")
+    d = sc.desc.contents
+    assert tuple(d.background) == (0.25, 0.25, 0.25)
+    assert list(d.nodes[0].params)[:6] == [1.0, 1.0, 1.0, 0.0, 1.0, 0.0]
+    assert list(d.nodes[1].params)[:4] == [-1.5, 20.0, 3.0, 2.0]
+    # scale then rotate then translate, folded left to right (sdl.rs:94-96)
+    m = np.array(list(d.nodes[1].o2w)).reshape(4, 4)
+    p = np.array([1.0, 0, 0, 1.0]) @ m
+    assert np.allclose(p[:3], [-1.0, 0.0, -2.0], atol=1e-12)
+    w2o = np.array(list(d.nodes[1].w2o)).reshape(4, 4)
+    assert np.allclose(m @ w2o, np.eye(4), atol=1e-12)
+
+
+@pytest.mark.parametrize("text", [
+    CAM,                                                            # no objects
+    "  options { background color black }\n" + CAM + "object { sphere { }" + MAT + "}",  # options only at offset 0
+    CAM + "object { sphere { radius .5 }" + MAT + "}",             # `.5` is not a float literal
+    CAM + "object { sphere { radius 1e3 }" + MAT + "}",            # exponent needs a fraction
+    CAM + "object { torus { radius 1 }" + MAT + "}",               # torus needs both radii
+    CAM + "object { sphere { radius 1 origin <0> }" + MAT + "}",   # field order is fixed
+    CAM + "object { sphere { } material { plastic } }",
+    CAM + "object { sphere { }" + MAT + "} trailing",
+    CAM + "/* a * b */ object { sphere { }" + MAT + "}",           # block comments cannot hold '*'
+])
+def test_grammar_rejections(rt, text):
+    with pytest.raises(rt.sdl.ParseError):
+        rt.parse(rt.Options(width=8, height=8), text, ".")
+
+
+def test_missing_assets_raise(rt):
+    o = rt.Options(width=8, height=8)
+    with pytest.raises(FileNotFoundError):
+        rt.parse(o, CAM + 'object { mesh { file "nope.obj" }' + MAT + "}", parity.ASSETS)
+    with pytest.raises(FileNotFoundError):
+        rt.parse(o, CAM + 'object { sphere { } material { lambertian texture { image "nope.jpg" 1.0 } } }', parity.ASSETS)
+
+
+def test_earth_texture_bytes(rt):
+    o = rt.Options(width=8, height=8)
+    sc = rt.parse_file(o, parity.scene_path("three-spheres"), parity.ASSETS)
+    d = sc.desc.contents
+    assert d.n_images == 1 and d.images[0].width == 756 and d.images[0].height == 378
+    assert [d.image_data[k] for k in range(3)] == [205, 206, 224]
+
+
+@pytest.mark.parametrize("w,h,tile,count", [(100, 70, 16, 3), (3840, 2160, 64, 8), (64, 64, 64, 2), (33, 9, 8, 5)])
+def test_shards_partition_the_image(rt, w, h, tile, count):
+    from raytracer_amd import system
+    o = rt.Options(width=w, height=h, tile_size=tile)
+    seen = np.zeros(w * h, dtype=np.int32)
+    sizes = []
+    for r in range(count):
+        m = system.shard_map(o, r, count)
+        assert len(m) == system.shard_pixels(o, r, count)
+        sizes.append(len(m))
+        np.add.at(seen, m[m >= 0], 1)
+    assert (seen == 1).all()
+    assert max(sizes) - min(sizes) <= tile * tile  # interleaved tiles: at most one tile apart
+    # one wave = one 8x8 block
+    m0 = system.shard_map(o, 0, count)
+    blk = m0[:64]
+    if (blk >= 0).all():
+        ys, xs = blk // w, blk % w
+        assert xs.max() - xs.min() == 7 and ys.max() - ys.min() == 7
+
+
+def test_tonemap_matches_reference_pixel_math(rt):
+    """main.rs:201-222 incl. its divide-by-(N+1) and saturating casts."""
+    vals = np.array([[0.0, 0.5, 2.0], [8.0, -1.0, np.nan], [1e-9, 1.0, 0.25]])
+    out = rt.tonemap(vals, 2.0)
+    ref = oracle_lib.tonemap(vals, 2.0)
+    assert np.array_equal(out, ref)
+    assert list(out[0]) == [0, int(np.sqrt(0.25) * 255.0), 255]
+    assert list(out[1]) == [255, 255, 255] or list(out[1])[0] == 255
+
+
+def test_no_gpu_is_a_loud_error(rt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sc = rt.parse_file(rt.Options(width=8, height=8), parity.scene_path("torus"), parity.ASSETS)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        rt.render(rt.Options(width=8, height=8), sc)
+
+
+def test_unsupported_and_invalid_descriptions(rt):
+    """Errors come back as status codes + rt_last_error, never as a crash."""
+    import descs
+    d = descs.Desc([{"kind": "sphere", "params": [0, 0, 0, 1]}])
+    d.objects[0].material = 7
+    h = C.c_void_p()
+    rc = rt.lib.rt_scene_create(d.ptr, C.byref(h))
+    assert rc == _capi.RT_ERR_INVALID and b"material" in rt.lib.rt_last_error()
+    assert rt.lib.rt_scene_create(None, C.byref(h)) == _capi.RT_ERR_INVALID
