@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     common = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=" + FP_CONTRACT, "-fno-math-errno", "-Wall",
-              "-Wno-unused-function"]
+              "-Wno-unused-function"] + os.environ.get("RT_EXTRA_FLAGS", "").split()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []

@@ -143,6 +143,8 @@ __device__ __noinline__ int torus_ends(const double *p, d3 o, d3 d, double *t, u
     return 0;
 }
 
+// TORUS = false leaves the quartic solver (and its registers) out of the kernel.
+template <bool TORUS>
 RT_DEV int leaf_ends(const DevLeaf &L, const LeafRay &ry, double *t, uint32_t *sub, Guards &gd)
 {
     const d3 o = ry.o, d = ry.d;
@@ -328,7 +330,9 @@ RT_DEV int leaf_ends(const DevLeaf &L, const LeafRay &ry, double *t, uint32_t *s
             return 2;
         }
     }
-    case DL_TORUS: return torus_ends(p, o, d, t, sub, gd);
+    case DL_TORUS:
+        if (TORUS) return torus_ends(p, o, d, t, sub, gd);
+        return 0;
     default: return 0;
     }
 }
@@ -624,12 +628,13 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
 }
 
 // Intervals of one leaf as world-space end points
+template <bool TORUS>
 RT_DEV void leaf_world_intervals(const DevLeaf &L, uint32_t rel, d3 ow, d3 dw, IvList &out, Guards &gd)
 {
     LeafRay ry = to_leaf(L, ow, dw);
     double t[4];
     uint32_t sub[4];
-    int n = leaf_ends(L, ry, t, sub, gd);
+    int n = leaf_ends<TORUS>(L, ry, t, sub, gd);
     out.n = n >> 1;
     for (int i = 0; i < 4; ++i) {
         if (i >= n) break;
@@ -653,7 +658,7 @@ __device__ __noinline__ bool csg_eval(const DevScene &sc, const DevObject &ob, d
                 return false;
             }
             uint32_t rel = (uint32_t)(word & 0xFFFFFF);
-            leaf_world_intervals(sc.leaves[ob.leaf0 + rel], rel, ow, dw, stack[sp], gd);
+            leaf_world_intervals<true>(sc.leaves[ob.leaf0 + rel], rel, ow, dw, stack[sp], gd);
             ++sp;
         } else {
             if (sp < 2) return false;
@@ -675,14 +680,25 @@ RT_DEV bool tri_hit(const double *__restrict__ tr, d3 o, d3 d, double &t, double
     d3 pvec = cross3(d, e2);
     double det = dot3(e1, pvec);
     if (det < 2.220446049250313e-16) return false; // f64::EPSILON: back faces and edge-on triangles
-    double inv_det = 1.0 / det;
+    // Most triangles of a leaf fail one of the tests below by a wide margin.  The numerators
+    // decide those cases without the f64 division (det > 0, so signs and the comparison with
+    // det carry over); only candidates within 1e-12 of a boundary reach the reference's
+    // exact arithmetic, which then decides as the reference does.
     d3 tvec = o - v0;
-    u = dot3(tvec, pvec) * inv_det;
-    if (u < 0.0 || u > 1.0) return false;
+    double un = dot3(tvec, pvec);
+    const double hi = det * (1.0 + 1e-12);
+    if (un < -1e-290 || un > hi) return false;
     d3 qvec = cross3(tvec, e1);
-    v = dot3(d, qvec) * inv_det;
+    double vn = dot3(d, qvec);
+    if (vn < -1e-290 || un + vn > hi) return false;
+    double tn = dot3(e2, qvec);
+    if (tn < -1e-290) return false;
+    double inv_det = 1.0 / det;
+    u = un * inv_det;
+    if (u < 0.0 || u > 1.0) return false;
+    v = vn * inv_det;
     if (v < 0.0 || (u + v) > 1.0) return false;
-    t = dot3(e2, qvec) * inv_det;
+    t = tn * inv_det;
     if (t < 0.0) return false;
     return true;
 }
@@ -706,9 +722,23 @@ RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
 
 // Nearest triangle (smallest t, lowest index on ties) = element 0 of the
 // reference's stable sort over all triangle hits (mesh.rs:54-64).
-__device__ __noinline__ bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 inv, double &best_t,
-                                          uint32_t &best_tri)
+//
+// Stack-based kd-tree walk, front to back.  The deferred far children live in
+// LDS, one 8-byte entry per level: (node, far bound of that cell as an f32
+// rounded up).  Cells are visited in ray order, so the near bound of a popped
+// cell is the far bound of the leaf just finished and need not be stored.
+// `stk` points at this lane's column: entry e is stk[e * RT_KD_LANES].
+#define RT_KD_LANES 256
+#ifdef RT_KD_STATS
+__device__ unsigned long long g_kd_iters, g_kd_tris, g_kd_rays;
+__device__ unsigned int g_kd_max;
+#endif
+RT_DEV bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 inv, uint2 *stk, double &best_t,
+                         uint32_t &best_tri)
 {
+#ifdef RT_KD_STATS
+    unsigned int st_iters = 0, st_tris = 0;
+#endif
     // clip the ray against the tight (padded) bounds
     double t0 = 0.0, t1 = 1.0e300;
     {
@@ -734,16 +764,17 @@ __device__ __noinline__ bool mesh_nearest(const DevScene &sc, const DevMesh &m, 
     best_t = 1.0e300;
     best_tri = 0xFFFFFFFFu;
 
-    uint32_t stack_node[DEV_KD_STACK];
-    double stack_tmin[DEV_KD_STACK], stack_tmax[DEV_KD_STACK];
     int sp = 0;
     uint32_t node = 0;
     double tmin = t0, tmax = t1;
-    const DevKdNode *kd = sc.kd + m.kd0;
-    const uint32_t *index = sc.kd_index + m.kd_index0;
-    const double *tris = sc.tris + (size_t)m.tri0 * 9;
-    for (int iter = 0; iter < 4096; ++iter) { // bounded: a tree of depth <= 30 never needs this many steps
+    const DevKdNode *__restrict__ kd = sc.kd + m.kd0;
+    const uint32_t *__restrict__ index = sc.kd_index + m.kd_index0;
+    const double *__restrict__ tris = sc.tris + (size_t)m.tri0 * 9;
+    for (int iter = 0; iter < 8192; ++iter) { // bounded: every step descends one level or pops one entry
         if (best_t < tmin) break;
+#ifdef RT_KD_STATS
+        ++st_iters;
+#endif
         DevKdNode nd = kd[node];
         uint32_t axis = nd.a & 3u;
         if (axis != 3u) {
@@ -762,9 +793,7 @@ __device__ __noinline__ bool mesh_nearest(const DevScene &sc, const DevMesh &m, 
                 node = second;
             } else {
                 if (sp < DEV_KD_STACK) {
-                    stack_node[sp] = second;
-                    stack_tmin[sp] = tplane - eps;
-                    stack_tmax[sp] = tmax;
+                    stk[sp * RT_KD_LANES] = make_uint2(second, __float_as_uint(__double2float_ru(tmax)));
                     ++sp;
                 }
                 node = first;
@@ -775,6 +804,9 @@ __device__ __noinline__ bool mesh_nearest(const DevScene &sc, const DevMesh &m, 
             for (uint32_t k = 0; k < cnt; ++k) {
                 uint32_t ti = index[first + k];
                 double t, u, v;
+#ifdef RT_KD_STATS
+                ++st_tris;
+#endif
                 if (tri_hit(tris + (size_t)ti * 9, o, d, t, u, v)) {
                     if (t < best_t || (t == best_t && ti < best_tri)) {
                         best_t = t;
@@ -785,10 +817,18 @@ __device__ __noinline__ bool mesh_nearest(const DevScene &sc, const DevMesh &m, 
             }
             if (sp == 0) break;
             --sp;
-            node = stack_node[sp];
-            tmin = stack_tmin[sp];
-            tmax = stack_tmax[sp];
+            uint2 e = stk[sp * RT_KD_LANES];
+            node = e.x;
+            // the stored bounds are f32 round-ups: step back by more than that rounding
+            tmin = tmax - (2.4e-7 * fabs(tmax) + 1e-9);
+            tmax = (double)__uint_as_float(e.y);
         }
     }
+#ifdef RT_KD_STATS
+    atomicAdd(&g_kd_iters, (unsigned long long)st_iters);
+    atomicAdd(&g_kd_tris, (unsigned long long)st_tris);
+    atomicAdd(&g_kd_rays, 1ull);
+    atomicMax(&g_kd_max, st_iters);
+#endif
     return found;
 }

@@ -132,4 +132,4 @@ struct DevScene {
 #define DEV_MAX_LEAVES_PER_OBJECT 256
 #define DEV_MAX_INTERVALS 6   // per list
 #define DEV_CSG_STACK 4       // lists alive at once
-#define DEV_KD_STACK 32
+#define DEV_KD_STACK 24       // kd-tree depth limit = LDS stack entries per lane

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -53,29 +54,95 @@ struct Box {
     double lo[3], hi[3];
 };
 
+// One reference to a triangle inside a cell: the triangle and the bounds of the
+// part of it that lies in the cell ("split clipping": without it the diagonal,
+// chunky triangles of LinkedTorus.obj end up in ten leaves each and no empty
+// space is ever cut away).
+struct KdRef {
+    uint32_t tri;
+    Box box;
+};
+
+} }
+int g_kd_reason[4];
+namespace rt_host { namespace {
+
 struct KdBuilder {
-    const std::vector<Box> &pb;
+    const std::vector<double> &verts; // 9 per triangle: v0, v1, v2 (absolute)
     std::vector<DevKdNode> &nodes;
     std::vector<uint32_t> &index;
     uint32_t index_base; // start of this mesh's index list
     int max_depth;
-    static constexpr double kIsect = 20.0, kTrav = 1.0, kEmptyBonus = 0.5;
+    double pad;
+    double kIsect = 20.0, kTrav = 15.0, kEmptyBonus = 0.5; // chosen by measurement on MI355X
+    size_t leaf_max = 1;
+    double min_empty = 0.1;
 
-    void make_leaf(const std::vector<uint32_t> &prims)
+    // bounds of (triangle clipped to `cell` grown by pad); false if nothing is left
+    bool clip(uint32_t tri, const Box &cell, Box &out) const
+    {
+        double poly[16][3], tmp[16][3];
+        int n = 3;
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) poly[v][k] = verts[(size_t)tri * 9 + v * 3 + k];
+        for (int axis = 0; axis < 3 && n > 0; ++axis) {
+            for (int side = 0; side < 2 && n > 0; ++side) {
+                const double plane = side == 0 ? cell.lo[axis] - pad : cell.hi[axis] + pad;
+                int m = 0;
+                for (int i = 0; i < n; ++i) {
+                    const double *a = poly[i], *b = poly[(i + 1) % n];
+                    bool ina = side == 0 ? a[axis] >= plane : a[axis] <= plane;
+                    bool inb = side == 0 ? b[axis] >= plane : b[axis] <= plane;
+                    if (ina) {
+                        for (int k = 0; k < 3; ++k) tmp[m][k] = a[k];
+                        ++m;
+                    }
+                    if (ina != inb) {
+                        double t = (plane - a[axis]) / (b[axis] - a[axis]);
+                        for (int k = 0; k < 3; ++k) tmp[m][k] = a[k] + t * (b[k] - a[k]);
+                        tmp[m][axis] = plane;
+                        ++m;
+                    }
+                }
+                n = m;
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
+            }
+        }
+        if (n == 0) return false;
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] = poly[0][k];
+            out.hi[k] = poly[0][k];
+        }
+        for (int i = 1; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                out.lo[k] = std::fmin(out.lo[k], poly[i][k]);
+                out.hi[k] = std::fmax(out.hi[k], poly[i][k]);
+            }
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] -= pad;
+            out.hi[k] += pad;
+        }
+        return true;
+    }
+
+    void make_leaf(const std::vector<KdRef> &prims)
     {
         DevKdNode n;
         n.split = 0.0;
         n.a = (uint32_t)(((index.size() - index_base) << 2) | 3u);
         n.b = (uint32_t)prims.size();
-        std::vector<uint32_t> sorted = prims;
+        std::vector<uint32_t> sorted;
+        for (const KdRef &r : prims) sorted.push_back(r.tri);
         std::sort(sorted.begin(), sorted.end());
         index.insert(index.end(), sorted.begin(), sorted.end());
         nodes.push_back(n);
     }
 
-    void build(const std::vector<uint32_t> &prims, const Box &box, int depth, int bad)
+    void build(const std::vector<KdRef> &prims, const Box &box, int depth, int bad)
     {
-        if (prims.size() <= 2 || depth >= max_depth) {
+        if (prims.size() <= leaf_max || depth >= max_depth) {
+            g_kd_reason[prims.size() <= leaf_max ? 0 : 1]++;
             make_leaf(prims);
             return;
         }
@@ -94,8 +161,8 @@ struct KdBuilder {
         std::vector<Edge> edges(prims.size() * 2);
         for (int axis = 0; axis < 3; ++axis) {
             for (size_t i = 0; i < prims.size(); ++i) {
-                edges[2 * i] = Edge{pb[prims[i]].lo[axis], true};
-                edges[2 * i + 1] = Edge{pb[prims[i]].hi[axis], false};
+                edges[2 * i] = Edge{std::fmax(prims[i].box.lo[axis], box.lo[axis]), true};
+                edges[2 * i + 1] = Edge{std::fmin(prims[i].box.hi[axis], box.hi[axis]), false};
             }
             std::sort(edges.begin(), edges.end(), [](const Edge &a, const Edge &b) {
                 if (a.t == b.t) return (int)a.start > (int)b.start;
@@ -109,7 +176,10 @@ struct KdBuilder {
                 if (t > box.lo[axis] && t < box.hi[axis]) {
                     double below_sa = 2.0 * (d[o0] * d[o1] + (t - box.lo[axis]) * (d[o0] + d[o1]));
                     double above_sa = 2.0 * (d[o0] * d[o1] + (box.hi[axis] - t) * (d[o0] + d[o1]));
-                    double eb = (n_above == 0 || n_below == 0) ? kEmptyBonus : 0.0;
+                    // the bonus for cutting away empty space applies only to a worthwhile slab:
+                    // sliver cuts would otherwise win every time and use up the depth budget
+                    double frac = n_below == 0 ? (t - box.lo[axis]) / d[axis] : (box.hi[axis] - t) / d[axis];
+                    double eb = ((n_above == 0 || n_below == 0) && frac >= min_empty) ? kEmptyBonus : 0.0;
                     double cost = kTrav + kIsect * (1.0 - eb) *
                                               (below_sa * inv_sa * (double)n_below + above_sa * inv_sa * (double)n_above);
                     if (cost < best_cost) {
@@ -123,16 +193,33 @@ struct KdBuilder {
         }
         if (best_cost > old_cost) ++bad;
         if (best_axis < 0 || (best_cost > 4.0 * old_cost && prims.size() < 16) || bad >= 3) {
+            g_kd_reason[2]++;
             make_leaf(prims);
             return;
         }
-        std::vector<uint32_t> below, above;
-        for (uint32_t p : prims) {
-            // closed on both sides: a triangle touching the plane is listed in both children
-            if (pb[p].lo[best_axis] <= best_split) below.push_back(p);
-            if (pb[p].hi[best_axis] >= best_split) above.push_back(p);
+        Box bl = box, bh = box;
+        bl.hi[best_axis] = best_split;
+        bh.lo[best_axis] = best_split;
+        std::vector<KdRef> below, above;
+        for (const KdRef &r : prims) {
+            // A reference whose (padded) bounds merely touch the plane stays on its own side:
+            // candidate planes are exactly such bounds, and listing the touching triangle on
+            // both sides would duplicate one reference at every split.
+            bool lo_side = r.box.lo[best_axis] < best_split, hi_side = r.box.hi[best_axis] > best_split;
+            if (!lo_side && !hi_side) lo_side = true; // flat on the plane
+            if (lo_side && hi_side) {
+                KdRef c;
+                c.tri = r.tri;
+                if (clip(r.tri, bl, c.box)) below.push_back(c);
+                if (clip(r.tri, bh, c.box)) above.push_back(c);
+            } else if (lo_side) {
+                below.push_back(r);
+            } else {
+                above.push_back(r);
+            }
         }
         if (below.size() == prims.size() && above.size() == prims.size()) {
+            g_kd_reason[3]++;
             make_leaf(prims);
             return;
         }
@@ -142,9 +229,6 @@ struct KdBuilder {
         n.a = (uint32_t)best_axis;
         n.b = 0;
         nodes.push_back(n);
-        Box bl = box, bh = box;
-        bl.hi[best_axis] = best_split;
-        bh.lo[best_axis] = best_split;
         build(below, bl, depth + 1, bad);
         nodes[me].a = (uint32_t)((nodes.size() << 2) | (uint32_t)best_axis);
         build(above, bh, depth + 1, bad);
@@ -376,6 +460,7 @@ struct Flattener {
             }
         }
         std::vector<Box> pb(m.n_triangles);
+        std::vector<double> tri_verts;
         for (uint32_t t = 0; t < m.n_triangles; ++t) {
             const uint32_t *tv = d->tri_v + 3 * (size_t)(m.first_triangle + t);
             const uint32_t *tn = d->tri_n + 3 * (size_t)(m.first_triangle + t);
@@ -384,6 +469,8 @@ struct Flattener {
                 if (tv[k] >= m.n_vertices || tn[k] >= m.n_normals) throw Err{RT_ERR_INVALID, "triangle index out of range"};
                 v[k] = d->vertices + 3 * (size_t)(m.first_vertex + tv[k]);
             }
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) tri_verts.push_back(v[c][k]);
             for (int k = 0; k < 3; ++k) out.tris.push_back(v[0][k]);
             for (int k = 0; k < 3; ++k) out.tris.push_back(v[1][k] - v[0][k]); // v0v1 (mesh.rs:74)
             for (int k = 0; k < 3; ++k) out.tris.push_back(v[2][k] - v[0][k]); // v0v2 (mesh.rs:75)
@@ -417,10 +504,18 @@ struct Flattener {
         dm.kd_index0 = (uint32_t)out.kd_index.size();
         std::vector<DevKdNode> nodes; // mesh-relative node indices
         int max_depth = (int)std::lround(8.0 + 1.3 * std::log2((double)std::max<uint32_t>(1u, m.n_triangles)));
-        if (max_depth > DEV_KD_STACK - 2) max_depth = DEV_KD_STACK - 2;
-        KdBuilder kb{pb, nodes, out.kd_index, dm.kd_index0, max_depth};
-        std::vector<uint32_t> all(m.n_triangles);
-        for (uint32_t t = 0; t < m.n_triangles; ++t) all[t] = t;
+        if (max_depth > DEV_KD_STACK - 1) max_depth = DEV_KD_STACK - 1;
+        KdBuilder kb{tri_verts, nodes, out.kd_index, dm.kd_index0, max_depth, pad};
+        if (const char *e = std::getenv("RT_KD_ISECT")) kb.kIsect = std::atof(e);     // tuning knobs, not API
+        if (const char *e = std::getenv("RT_KD_LEAF")) kb.leaf_max = (size_t)std::atoi(e);
+        if (const char *e = std::getenv("RT_KD_EMPTY")) kb.kEmptyBonus = std::atof(e);
+        if (const char *e = std::getenv("RT_KD_TRAV")) kb.kTrav = std::atof(e);
+        if (const char *e = std::getenv("RT_KD_MINEMPTY")) kb.min_empty = std::atof(e);
+        std::vector<KdRef> all(m.n_triangles);
+        for (uint32_t t = 0; t < m.n_triangles; ++t) {
+            all[t].tri = t;
+            all[t].box = pb[t];
+        }
         kb.build(all, root, 0, 0);
         out.kd.insert(out.kd.end(), nodes.begin(), nodes.end());
         out.meshes.push_back(dm);

@@ -78,18 +78,45 @@ RT_DEV uint32_t wave_append(bool alive, uint32_t *counter)
     return base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
 }
 
+// Append with one atomic per workgroup: a single counter word takes about 90 atomics per
+// microsecond on this chip, so a per-wave atomic caps a pass at ~6 G appended rays/s; with
+// 1024-thread workgroups the counter is out of the picture.  Called by every thread of the
+// block, in block-uniform control flow.  `lds` holds blockDim.x / 64 + 1 words.
+RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
+{
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (lane_id() == 0) lds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; ++w) {
+            uint32_t c = lds[w];
+            lds[w] = total;
+            total += c;
+        }
+        lds[n_waves] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t at = lds[n_waves] + lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+    __syncthreads();
+    return at;
+}
+
+#define RT_BLOCK_WIDE 1024 // ray generation and shading: light on registers, heavy on queue appends
+
 // ------------------------------------------------------------------ ray generation
-__global__ void __launch_bounds__(RT_BLOCK) k_raygen(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots,
+__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_raygen(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots,
                                                       uint32_t s_i, uint32_t s_j, double recip_sqrt_spp, PassParams pp,
                                                       RayQueue q, uint32_t *count)
 {
+    __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
-    for (uint32_t base = wave_first; base < n_slots; base += stride) {
-        uint32_t slot = base + lane_id();
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_slots; base += stride) {
+        uint32_t slot = base + threadIdx.x;
         uint32_t x = 0, y = 0;
         bool valid = slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y);
-        uint32_t at = wave_append(valid, count);
+        uint32_t at = block_append(valid, count, append_lds);
         if (!valid) continue;
         uint32_t pixel = y * g.width + x;
         // get_stratified_ray (system.rs:237-242)
@@ -155,13 +182,14 @@ RT_DEV Candidate pick_from_list(const IvList &l, int mode)
     return c;
 }
 
+template <bool TORUS>
 RT_DEV Candidate eval_leaf_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
 {
     const DevLeaf &L = sc.leaves[ob.leaf0];
     LeafRay ry = to_leaf(L, o, d);
     double t[4];
     uint32_t sub[4];
-    int n = leaf_ends(L, ry, t, sub, gd);
+    int n = leaf_ends<TORUS>(L, ry, t, sub, gd);
     Candidate c;
     c.ok = false;
     c.t = 0.0;
@@ -202,8 +230,9 @@ __device__ __noinline__ Candidate eval_csg_object(const DevScene &sc, const DevO
     return pick_from_list(res, ob.mode);
 }
 
-// Composite::intersect over Mesh children (composite.rs:20-34, mesh.rs:116-128)
-__device__ __noinline__ Candidate eval_mesh_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d)
+// Composite::intersect over Mesh children (composite.rs:20-34, mesh.rs:116-128).
+// `stk`: this lane's kd stack column in LDS.
+RT_DEV Candidate eval_mesh_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, uint2 *stk)
 {
     Candidate c;
     c.ok = false;
@@ -219,7 +248,7 @@ __device__ __noinline__ Candidate eval_mesh_object(const DevScene &sc, const Dev
         if (!mesh_box_hit(m, ry.o, inv)) continue;
         double t;
         uint32_t tri;
-        if (mesh_nearest(sc, m, ry.o, ry.d, inv, t, tri)) {
+        if (mesh_nearest(sc, m, ry.o, ry.d, inv, stk, t, tri)) {
             if (!found || t < best) { // min_by keeps the first minimum
                 best = t;
                 c.aux = ((uint32_t)mi << 24) | (tri & 0xFFFFFFu);
@@ -234,7 +263,19 @@ __device__ __noinline__ Candidate eval_mesh_object(const DevScene &sc, const Dev
     return c;
 }
 
+// does the ray pass the Mesh::new box of any mesh of this object?
+RT_DEV bool mesh_object_box_hit(const DevScene &sc, const DevObject &ob, d3 o, d3 d)
+{
+    const DevLeaf &F = sc.leaves[ob.frame];
+    LeafRay ry = to_leaf(F, o, d);
+    d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
+    bool any = false;
+    for (int mi = 0; mi < ob.n_meshes; ++mi) any = any || mesh_box_hit(sc.meshes[ob.mesh0 + mi], ry.o, inv);
+    return any;
+}
+
 // HomogenousMedium::intersect (homogenous_medium.rs:29-57)
+template <bool CSG, bool TORUS>
 __device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
                                                      d3 d, const PassParams &pp, uint32_t pixel, Guards &gd)
 {
@@ -249,8 +290,8 @@ __device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const D
     IvList res;
     res.n = 0;
     if (ob.prog_len == 0) {
-        leaf_world_intervals(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
-    } else if (!csg_eval(sc, ob, o, d, res, gd)) {
+        leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
+    } else if (!CSG || !csg_eval(sc, ob, o, d, res, gd)) {
         return c;
     }
     if (res.n == 0) return c;
@@ -274,75 +315,141 @@ __device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const D
     return c;
 }
 
+// Pass 1 of the nearest-hit search: every object except the triangle work.
+// A ray that passes the bounding box of a mesh object is appended to
+// `mesh_queue`; k_mesh then walks the kd-trees with full waves and merges its
+// result into the hit record.  CSG / MEDIUM prune code (and registers) the
+// scene does not need.
+template <bool CSG, bool MEDIUM, bool TORUS>
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
-                                                         PassParams pp, int32_t *primary_ids, uint32_t *guards_out)
+                                                         PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
+                                                         uint32_t *mesh_queue, uint32_t *mesh_count)
 {
+    __shared__ uint32_t append_lds[RT_BLOCK / 64 + 1];
     const uint32_t count = *count_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
     Guards gd;
     for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
     gd.overflow = 0u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        bool wants_mesh = false;
+        if (i < count) {
+            d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+            d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+            uint32_t pixel = q.pixel[i];
+
+            // Ray::trace (system.rs:122-133): first object wins ties, t must be < f64::MAX
+            double best_t = DBL_MAX;
+            int best_obj = -1;
+            uint32_t best_aux = 0u;
+            for (int k = 0; k < sc.n_objects; ++k) {
+                const DevObject &ob = sc.objects[k];
+                Candidate c;
+                c.ok = false;
+                c.t = 0.0;
+                c.aux = 0u;
+                switch (ob.kind) {
+                case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
+                case DO_CSG:
+                    if (CSG) c = eval_csg_object(sc, ob, o, d, gd);
+                    break;
+                case DO_MESH: wants_mesh = wants_mesh || mesh_object_box_hit(sc, ob, o, d); break;
+                default:
+                    if (MEDIUM) c = eval_medium_object<CSG, TORUS>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
+                    break;
+                }
+                // Object::intersect keeps t >= 0 (object.rs:50-54)
+                if (c.ok && c.t >= 0.0 && c.t < DBL_MAX && (best_obj < 0 || c.t < best_t)) {
+                    best_t = c.t;
+                    best_obj = k;
+                    best_aux = c.aux;
+                }
+            }
+
+            d3 n = mk3(0.0, 0.0, 0.0);
+            double u = 0.0, v = 0.0;
+            if (best_obj >= 0) {
+                const DevObject &ob = sc.objects[best_obj];
+                const bool need_uv = ob.needs_uv || pp.force_uv;
+                d3 pw = o + d * best_t;
+                if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
+                    const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
+                    LeafRay ry = to_leaf(L, o, d);
+                    d3 ql = L.identity ? pw : xf_point(L.W, pw);
+                    d3 nl;
+                    leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
+                    n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
+                    if (best_aux & TAG_NEG) n = -n;
+                } else {
+                    const DevLeaf &F = sc.leaves[ob.frame];
+                    n = F.identity ? mk3(1.0, 0.0, 0.0) : normalize3(xf_normal(F.W, mk3(1.0, 0.0, 0.0)));
+                }
+            }
+            hit.t[i] = best_obj >= 0 ? best_t : -1.0;
+            hit.n[0][i] = n.x;
+            hit.n[1][i] = n.y;
+            hit.n[2][i] = n.z;
+            hit.uv[0][i] = u;
+            hit.uv[1][i] = v;
+            hit.obj[i] = best_obj;
+            if (primary_ids) primary_ids[q.slot[i]] = best_obj;
+        }
+        uint32_t at = block_append(wants_mesh, mesh_count, append_lds);
+        if (wants_mesh) mesh_queue[at] = i;
+    }
+    for (int k = 0; k < 5; ++k)
+        if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
+    if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
+}
+
+// Pass 2: the rays queued by k_intersect against the mesh objects.  A mesh hit
+// replaces the recorded hit when it is nearer, or equally near and earlier in
+// the object list - the order Ray::trace's min_by would have seen.
+__global__ void __launch_bounds__(RT_BLOCK) k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
+                                                    const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids)
+{
+    __shared__ uint2 kd_stack[DEV_KD_STACK * RT_KD_LANES];
+    uint2 *stk = kd_stack + threadIdx.x;
+    const uint32_t count = *mesh_count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        const uint32_t i = mesh_queue[j];
         d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
         d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
-        uint32_t pixel = q.pixel[i];
-
-        // Ray::trace (system.rs:122-133): first object wins ties, t must be < f64::MAX
-        double best_t = DBL_MAX;
-        int best_obj = -1;
+        int best_obj = hit.obj[i];
+        double best_t = best_obj >= 0 ? hit.t[i] : DBL_MAX;
         uint32_t best_aux = 0u;
+        bool replaced = false;
         for (int k = 0; k < sc.n_objects; ++k) {
             const DevObject &ob = sc.objects[k];
-            Candidate c;
-            switch (ob.kind) {
-            case DO_LEAF: c = eval_leaf_object(sc, ob, o, d, gd); break;
-            case DO_CSG: c = eval_csg_object(sc, ob, o, d, gd); break;
-            case DO_MESH: c = eval_mesh_object(sc, ob, o, d); break;
-            default: c = eval_medium_object(sc, ob, (uint32_t)k, o, d, pp, pixel, gd); break;
-            }
-            // Object::intersect keeps t >= 0 (object.rs:50-54)
-            if (c.ok && c.t >= 0.0 && c.t < DBL_MAX && (best_obj < 0 || c.t < best_t)) {
+            if (ob.kind != DO_MESH) continue;
+            Candidate c = eval_mesh_object(sc, ob, o, d, stk);
+            if (c.ok && c.t >= 0.0 && c.t < DBL_MAX &&
+                (best_obj < 0 || c.t < best_t || (c.t == best_t && k < best_obj))) {
                 best_t = c.t;
                 best_obj = k;
                 best_aux = c.aux;
+                replaced = true;
             }
         }
-
-        d3 n = mk3(0.0, 0.0, 0.0);
-        double u = 0.0, v = 0.0;
-        if (best_obj >= 0) {
-            const DevObject &ob = sc.objects[best_obj];
-            const bool need_uv = ob.needs_uv || pp.force_uv;
-            d3 pw = o + d * best_t;
-            if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
-                const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
-                LeafRay ry = to_leaf(L, o, d);
-                d3 ql = L.identity ? pw : xf_point(L.W, pw);
-                d3 nl;
-                leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
-                n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
-                if (best_aux & TAG_NEG) n = -n;
-            } else if (ob.kind == DO_MESH) {
-                const DevLeaf &F = sc.leaves[ob.frame];
-                const DevMesh &m = sc.meshes[ob.mesh0 + (best_aux >> 24)];
-                LeafRay ry = to_leaf(F, o, d);
-                uint32_t tri = best_aux & 0xFFFFFFu;
-                double tt = 0.0;
-                tri_hit(sc.tris + ((size_t)m.tri0 + tri) * 9, ry.o, ry.d, tt, u, v);
-                const uint32_t *tn = sc.tri_n + ((size_t)m.tri0 + tri) * 3;
-                const double *nb = sc.normals + (size_t)m.normal0 * 3;
-                d3 n0 = mk3(nb[3 * tn[0]], nb[3 * tn[0] + 1], nb[3 * tn[0] + 2]);
-                d3 n1 = mk3(nb[3 * tn[1]], nb[3 * tn[1] + 1], nb[3 * tn[1] + 2]);
-                d3 n2 = mk3(nb[3 * tn[2]], nb[3 * tn[2] + 1], nb[3 * tn[2] + 2]);
-                // mesh.rs:102-106
-                d3 nl = m.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
-                n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
-            } else {
-                const DevLeaf &F = sc.leaves[ob.frame];
-                n = F.identity ? mk3(1.0, 0.0, 0.0) : normalize3(xf_normal(F.W, mk3(1.0, 0.0, 0.0)));
-            }
-        }
-        hit.t[i] = best_obj >= 0 ? best_t : -1.0;
+        if (!replaced) continue;
+        const DevObject &ob = sc.objects[best_obj];
+        const DevLeaf &F = sc.leaves[ob.frame];
+        const DevMesh &m = sc.meshes[ob.mesh0 + (best_aux >> 24)];
+        LeafRay ry = to_leaf(F, o, d);
+        uint32_t tri = best_aux & 0xFFFFFFu;
+        double tt = 0.0, u = 0.0, v = 0.0;
+        tri_hit(sc.tris + ((size_t)m.tri0 + tri) * 9, ry.o, ry.d, tt, u, v);
+        const uint32_t *tn = sc.tri_n + ((size_t)m.tri0 + tri) * 3;
+        const double *nb = sc.normals + (size_t)m.normal0 * 3;
+        d3 n0 = mk3(nb[3 * tn[0]], nb[3 * tn[0] + 1], nb[3 * tn[0] + 2]);
+        d3 n1 = mk3(nb[3 * tn[1]], nb[3 * tn[1] + 1], nb[3 * tn[1] + 2]);
+        d3 n2 = mk3(nb[3 * tn[2]], nb[3 * tn[2] + 1], nb[3 * tn[2] + 2]);
+        // mesh.rs:102-106
+        d3 nl = m.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
+        d3 n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
+        hit.t[i] = best_t;
         hit.n[0][i] = n.x;
         hit.n[1][i] = n.y;
         hit.n[2][i] = n.z;
@@ -351,9 +458,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q,
         hit.obj[i] = best_obj;
         if (primary_ids) primary_ids[q.slot[i]] = best_obj;
     }
-    for (int k = 0; k < 5; ++k)
-        if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
-    if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
 }
 
 // ------------------------------------------------------------------ shading
@@ -437,15 +541,15 @@ RT_DEV d3 refract(d3 inc, d3 nrm, double ior)
 
 RT_DEV d3 reflect3(d3 d, d3 n) { return d - (n * 2.0) * dot3(d, n); } // direction.rs:75-77
 
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
+__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
                                                      RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
 {
+    __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
     const uint32_t count = *count_in_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
-    for (uint32_t base = wave_first; base < count; base += stride) {
-        const uint32_t i = base + lane_id();
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+        const uint32_t i = base + threadIdx.x;
         const bool active = i < count;
         bool alive = false;
         d3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0), thr = mk3(0, 0, 0);
@@ -532,7 +636,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RayQueue qin, c
                 alive = true;
             }
         }
-        uint32_t at = wave_append(alive, count_out);
+        uint32_t at = block_append(alive, count_out, append_lds);
         if (alive) {
             qout.o[0][at] = no.x;
             qout.o[1][at] = no.y;
@@ -610,7 +714,9 @@ struct rt_scene {
     void *ws = nullptr;
     RayQueue q[2];
     HitBuf hit;
-    uint32_t *d_counts = nullptr; // max_depth + 2 counters
+    bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
+    uint32_t *mesh_queue = nullptr; // ray indices that need the kd-trees this pass
+    uint32_t *d_counts = nullptr; // 2 x (max_depth + 2): live rays per depth, then mesh-queue lengths per depth
     uint32_t counts_cap = 0;
     uint32_t *d_guards = nullptr; // 6
     uint32_t *h_pinned = nullptr; // readback slot
@@ -643,7 +749,7 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         free_workspace(s);
         // 2 queues x (9 f64 + 2 u32) + hits (6 f64 + 1 i32), each array 256-B aligned
         size_t n = (cap + 63) & ~(size_t)63;
-        size_t bytes = n * (2 * (9 * 8 + 2 * 4) + 6 * 8 + 4);
+        size_t bytes = n * (2 * (9 * 8 + 2 * 4) + 6 * 8 + 4 + 4);
         HIP_TRY(hipMalloc(&s->ws, bytes));
         char *p = (char *)s->ws;
         auto take = [&](size_t elem) {
@@ -664,12 +770,13 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
             s->q[k].pixel = (uint32_t *)take(4);
         }
         s->hit.obj = (int32_t *)take(4);
+        s->mesh_queue = (uint32_t *)take(4);
         s->cap = cap;
     }
     if (max_depth + 2 > s->counts_cap) {
         if (s->d_counts) (void)hipFree(s->d_counts);
         s->d_counts = nullptr;
-        HIP_TRY(hipMalloc((void **)&s->d_counts, (max_depth + 2) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s->d_counts, 2 * (max_depth + 2) * sizeof(uint32_t)));
         if (s->h_pinned) (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
         HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (max_depth + 2 + 8) * sizeof(uint32_t), hipHostMallocDefault));
@@ -724,6 +831,13 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     if ((rc = upload(s, flat.textures, &s->dev.textures))) return fail(rc);
     if ((rc = upload(s, flat.image_data, &s->dev.image_data))) return fail(rc);
     s->dev.n_objects = (int32_t)flat.objects.size();
+    for (const DevObject &ob : flat.objects) {
+        if (ob.kind == DO_CSG || (ob.kind == DO_MEDIUM && ob.prog_len > 0)) s->has_csg = true;
+        if (ob.kind == DO_MEDIUM) s->has_medium = true;
+        if (ob.kind == DO_MESH) s->has_mesh = true;
+    }
+    for (const DevLeaf &L : flat.leaves)
+        if (L.kind == DL_TORUS) s->has_torus = true;
     for (int k = 0; k < 3; ++k) s->dev.background[k] = flat.background[k];
     s->dev.cam_fov_factor = flat.cam_fov_factor;
     std::memcpy(s->dev.cam_c2w, flat.cam_c2w, sizeof(flat.cam_c2w));
@@ -755,6 +869,14 @@ static uint32_t grid_for(uint64_t n)
     return (uint32_t)b;
 }
 
+static uint32_t grid_for_wide(uint64_t n)
+{
+    uint64_t b = (n + RT_BLOCK_WIDE - 1) / RT_BLOCK_WIDE;
+    if (b < 1) b = 1;
+    if (b > 256 * 2) b = 256 * 2;
+    return (uint32_t)b;
+}
+
 static int check_options(const rt_options *o)
 {
     if (!o || o->width == 0 || o->height == 0 || o->samples == 0) {
@@ -771,6 +893,30 @@ static int check_options(const rt_options *o)
         return RT_ERR_INVALID;
     }
     return RT_OK;
+}
+
+// nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the kd-tree pass
+static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
+                             uint32_t *mesh_count, const PassParams &pp, int32_t *ids)
+{
+    dim3 grid(grid_for(live)), block(RT_BLOCK);
+#define LAUNCH_I(C, M, T)                                                                                              \
+    hipLaunchKernelGGL((k_intersect<C, M, T>), grid, block, 0, st, s->dev, q, count_ptr, s->hit, pp, ids, s->d_guards, \
+                       s->mesh_queue, mesh_count)
+    const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
+    switch (variant) {
+    case 0: LAUNCH_I(false, false, false); break;
+    case 1: LAUNCH_I(false, false, true); break;
+    case 2: LAUNCH_I(false, true, false); break;
+    case 3: LAUNCH_I(false, true, true); break;
+    case 4: LAUNCH_I(true, false, false); break;
+    case 5: LAUNCH_I(true, false, true); break;
+    case 6: LAUNCH_I(true, true, false); break;
+    default: LAUNCH_I(true, true, true); break;
+    }
+#undef LAUNCH_I
+    if (s->has_mesh)
+        hipLaunchKernelGGL(k_mesh, grid, block, 0, st, s->dev, q, s->mesh_queue, mesh_count, s->hit, ids);
 }
 
 typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
@@ -830,10 +976,10 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 hipLaunchKernelGGL(k_fill_background, dim3((n_slots + 255) / 256), dim3(256), 0, st, s->dev, g, rank,
                                    n_slots, d_rgb);
             } else {
-                HIP_TRY(hipMemsetAsync(s->d_counts, 0, (opts->max_depth + 2) * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * (opts->max_depth + 2) * sizeof(uint32_t), st));
                 RT_TRACE("launching raygen grid %u", grid_for(n_slots));
                 HIP_TRY(hipEventRecord(s->evk[3], st));
-                hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_slots)), dim3(RT_BLOCK), 0, st, s->dev, g, rank, n_slots,
+                hipLaunchKernelGGL(k_raygen, dim3(grid_for_wide(n_slots)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, g, rank, n_slots,
                                    s_i, s_j, recip, pp, s->q[0], s->d_counts);
                 RT_TRACE("raygen launched");
                 uint32_t live = n_slots; // upper bound until read back
@@ -842,10 +988,10 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
                     HIP_TRY(hipEventRecord(s->evk[0], st));
-                    hipLaunchKernelGGL(k_intersect, dim3(grid_for(live)), dim3(RT_BLOCK), 0, st, s->dev, s->q[cur],
-                                       s->d_counts + depth, s->hit, pp, ids, s->d_guards);
+                    launch_intersect(s, st, live, s->q[cur], s->d_counts + depth,
+                                     s->d_counts + (opts->max_depth + 2) + depth, pp, ids);
                     HIP_TRY(hipEventRecord(s->evk[1], st));
-                    hipLaunchKernelGGL(k_shade, dim3(grid_for(live)), dim3(RT_BLOCK), 0, st, s->dev, s->q[cur],
+                    hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, s->q[cur],
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
                     HIP_TRY(hipEventRecord(s->evk[2], st));
                     local.bounce_passes++;
@@ -891,6 +1037,18 @@ finished:
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
     local.interval_overflow = s->h_pinned[5];
+#ifdef RT_KD_STATS
+    {
+        unsigned long long it = 0, tr = 0, ry = 0;
+        unsigned int mx = 0;
+        (void)hipMemcpyFromSymbol(&it, HIP_SYMBOL(g_kd_iters), 8);
+        (void)hipMemcpyFromSymbol(&tr, HIP_SYMBOL(g_kd_tris), 8);
+        (void)hipMemcpyFromSymbol(&ry, HIP_SYMBOL(g_kd_rays), 8);
+        (void)hipMemcpyFromSymbol(&mx, HIP_SYMBOL(g_kd_max), 4);
+        fprintf(stderr, "[kd] traversals %llu  steps/ray %.1f  tris/ray %.1f  max steps %u\n", ry, ry ? (double)it / ry : 0.0,
+                ry ? (double)tr / ry : 0.0, mx);
+    }
+#endif
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     local.ms_device = ms;
@@ -1029,8 +1187,8 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     pp.max_depth = 1;
     pp.force_uv = 1;
     pp.bias = 0.0;
-    hipLaunchKernelGGL(k_intersect, dim3(grid_for(n)), dim3(RT_BLOCK), 0, nullptr, s->dev, s->q[0], s->d_counts, s->hit,
-                       pp, (int32_t *)nullptr, s->d_guards);
+    HIP_TRY(hipMemset(s->d_counts + 3, 0, sizeof(uint32_t)));
+    launch_intersect(s, nullptr, n32, s->q[0], s->d_counts, s->d_counts + 3, pp, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<int32_t> obj(n);
