@@ -728,16 +728,18 @@ RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
 // rounded up).  Cells are visited in ray order, so the near bound of a popped
 // cell is the far bound of the leaf just finished and need not be stored.
 // `stk` points at this lane's column: entry e is stk[e * RT_KD_LANES].
-#define RT_KD_LANES 256
+#define RT_KD_LANES 128 // = threads per k_mesh workgroup
 #ifdef RT_KD_STATS
 __device__ unsigned long long g_kd_iters, g_kd_tris, g_kd_rays;
 __device__ unsigned int g_kd_max;
+__device__ unsigned long long g_kd_cyc, g_kd_maxcyc, g_kd_maxcyc_steps;
 #endif
 RT_DEV bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 inv, uint2 *stk, double &best_t,
                          uint32_t &best_tri)
 {
 #ifdef RT_KD_STATS
     unsigned int st_iters = 0, st_tris = 0;
+    long long st_t0 = clock64();
 #endif
     // clip the ray against the tight (padded) bounds
     double t0 = 0.0, t1 = 1.0e300;
@@ -767,24 +769,25 @@ RT_DEV bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 in
     int sp = 0;
     uint32_t node = 0;
     double tmin = t0, tmax = t1;
-    const DevKdNode *__restrict__ kd = sc.kd + m.kd0;
-    const uint32_t *__restrict__ index = sc.kd_index + m.kd_index0;
-    const double *__restrict__ tris = sc.tris + (size_t)m.tri0 * 9;
-    for (int iter = 0; iter < 8192; ++iter) { // bounded: every step descends one level or pops one entry
-        if (best_t < tmin) break;
+    const uint4 *__restrict__ kd = reinterpret_cast<const uint4 *>(sc.kd + m.kd0); // one 16-byte load per node
+    const double *__restrict__ leaf_tris = sc.leaf_tris + (size_t)m.kd_index0 * 10;
+    // "while-while": all lanes first walk down to their next leaf (cheap steps), then the wave
+    // tests triangles together (the expensive part), instead of paying for both in every step.
+    for (int round = 0; round < 4096; ++round) { // bounded: every round consumes one leaf
+        uint4 raw = kd[node];
+        for (int step = 0; step < 64 && (raw.z & 3u) != 3u; ++step) { // depth <= DEV_KD_STACK
 #ifdef RT_KD_STATS
-        ++st_iters;
+            ++st_iters;
 #endif
-        DevKdNode nd = kd[node];
-        uint32_t axis = nd.a & 3u;
-        if (axis != 3u) {
+            const uint32_t axis = raw.z & 3u, right = raw.z >> 2;
+            const double split = __hiloint2double((int)raw.y, (int)raw.x);
             double oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
             double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
             double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-            double tplane = (nd.split - oa) * ia;
-            bool below_first = (oa < nd.split) || (oa == nd.split && da <= 0.0);
-            uint32_t first = below_first ? node + 1u : (nd.a >> 2);
-            uint32_t second = below_first ? (nd.a >> 2) : node + 1u;
+            double tplane = (split - oa) * ia;
+            bool below_first = (oa < split) || (oa == split && da <= 0.0);
+            uint32_t first = below_first ? node + 1u : right;
+            uint32_t second = below_first ? right : node + 1u;
             // slack: a hit within rounding distance of the plane is searched on both sides
             double eps = 1e-9 * (fabs(tplane) + 1.0);
             if (tplane > tmax + eps || tplane <= 0.0) {
@@ -799,15 +802,18 @@ RT_DEV bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 in
                 node = first;
                 tmax = tplane + eps;
             }
-        } else {
-            uint32_t first = nd.a >> 2, cnt = nd.b;
+            raw = kd[node];
+        }
+        if ((raw.z & 3u) == 3u) {
+            const uint32_t first = raw.z >> 2, cnt = raw.w;
             for (uint32_t k = 0; k < cnt; ++k) {
-                uint32_t ti = index[first + k];
+                const double *__restrict__ rec = leaf_tris + (size_t)(first + k) * 10;
+                const uint32_t ti = (uint32_t)__double2loint(rec[9]);
                 double t, u, v;
 #ifdef RT_KD_STATS
                 ++st_tris;
 #endif
-                if (tri_hit(tris + (size_t)ti * 9, o, d, t, u, v)) {
+                if (tri_hit(rec, o, d, t, u, v)) {
                     if (t < best_t || (t == best_t && ti < best_tri)) {
                         best_t = t;
                         best_tri = ti;
@@ -815,20 +821,24 @@ RT_DEV bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 in
                     }
                 }
             }
-            if (sp == 0) break;
-            --sp;
-            uint2 e = stk[sp * RT_KD_LANES];
-            node = e.x;
-            // the stored bounds are f32 round-ups: step back by more than that rounding
-            tmin = tmax - (2.4e-7 * fabs(tmax) + 1e-9);
-            tmax = (double)__uint_as_float(e.y);
         }
+        if (sp == 0) break;
+        --sp;
+        uint2 e = stk[sp * RT_KD_LANES];
+        node = e.x;
+        // the stored bounds are f32 round-ups: step back by more than that rounding
+        tmin = tmax - (2.4e-7 * fabs(tmax) + 1e-9);
+        tmax = (double)__uint_as_float(e.y);
+        if (best_t < tmin) break; // every remaining cell lies beyond the hit
     }
 #ifdef RT_KD_STATS
     atomicAdd(&g_kd_iters, (unsigned long long)st_iters);
     atomicAdd(&g_kd_tris, (unsigned long long)st_tris);
     atomicAdd(&g_kd_rays, 1ull);
     atomicMax(&g_kd_max, st_iters);
+    unsigned long long cyc = (unsigned long long)(clock64() - st_t0);
+    atomicAdd(&g_kd_cyc, cyc);
+    atomicMax(&g_kd_maxcyc, cyc);
 #endif
     return found;
 }

@@ -117,6 +117,7 @@ struct DevScene {
     const DevKdNode *kd;
     const uint32_t *kd_index;
     const double *tris;    // 9 per triangle
+    const double *leaf_tris; // 10 per kd leaf reference, in leaf order: the 9 above + the triangle index (low word)
     const uint32_t *tri_n; // 3 per triangle (normal indices, mesh-relative)
     const double *normals; // xyz
     const DevMaterial *materials;
@@ -132,4 +133,4 @@ struct DevScene {
 #define DEV_MAX_LEAVES_PER_OBJECT 256
 #define DEV_MAX_INTERVALS 6   // per list
 #define DEV_CSG_STACK 4       // lists alive at once
-#define DEV_KD_STACK 24       // kd-tree depth limit = LDS stack entries per lane
+#define DEV_KD_STACK 20       // kd-tree depth limit = LDS stack entries per lane

@@ -518,6 +518,15 @@ struct Flattener {
         }
         kb.build(all, root, 0, 0);
         out.kd.insert(out.kd.end(), nodes.begin(), nodes.end());
+        // leaf-ordered copies of the triangle records: a leaf's triangles are then one
+        // contiguous run, with no index indirection in the traversal's dependent-load chain
+        for (size_t e = dm.kd_index0; e < out.kd_index.size(); ++e) {
+            const uint32_t t = out.kd_index[e];
+            for (int k = 0; k < 9; ++k) out.leaf_tris.push_back(out.tris[((size_t)dm.tri0 + t) * 9 + k]);
+            double tag = 0.0;
+            std::memcpy(&tag, &t, sizeof(t));
+            out.leaf_tris.push_back(tag);
+        }
         out.meshes.push_back(dm);
         ++obj.n_meshes;
     }

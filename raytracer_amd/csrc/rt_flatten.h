@@ -16,6 +16,7 @@ struct FlatScene {
     std::vector<DevKdNode> kd;
     std::vector<uint32_t> kd_index;
     std::vector<double> tris;
+    std::vector<double> leaf_tris;
     std::vector<uint32_t> tri_n;
     std::vector<double> normals;
     std::vector<DevMaterial> materials;

@@ -403,10 +403,39 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q,
     if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
 }
 
+// normal / uv of a mesh hit (mesh.rs:97-112 + the Composite's to_world) into the hit record
+RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &hit, int32_t *primary_ids, uint32_t i,
+                           d3 o, d3 d, double best_t, int best_obj, uint32_t best_aux)
+{
+    const DevObject &ob = sc.objects[best_obj];
+    const DevLeaf &F = sc.leaves[ob.frame];
+    const DevMesh &m = sc.meshes[ob.mesh0 + (best_aux >> 24)];
+    LeafRay ry = to_leaf(F, o, d);
+    uint32_t tri = best_aux & 0xFFFFFFu;
+    double tt = 0.0, u = 0.0, v = 0.0;
+    tri_hit(sc.tris + ((size_t)m.tri0 + tri) * 9, ry.o, ry.d, tt, u, v);
+    const uint32_t *tn = sc.tri_n + ((size_t)m.tri0 + tri) * 3;
+    const double *nb = sc.normals + (size_t)m.normal0 * 3;
+    d3 n0 = mk3(nb[3 * tn[0]], nb[3 * tn[0] + 1], nb[3 * tn[0] + 2]);
+    d3 n1 = mk3(nb[3 * tn[1]], nb[3 * tn[1] + 1], nb[3 * tn[1] + 2]);
+    d3 n2 = mk3(nb[3 * tn[2]], nb[3 * tn[2] + 1], nb[3 * tn[2] + 2]);
+    // mesh.rs:102-106
+    d3 nl = m.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
+    d3 n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
+    hit.t[i] = best_t;
+    hit.n[0][i] = n.x;
+    hit.n[1][i] = n.y;
+    hit.n[2][i] = n.z;
+    hit.uv[0][i] = u;
+    hit.uv[1][i] = v;
+    hit.obj[i] = best_obj;
+    if (primary_ids) primary_ids[q.slot[i]] = best_obj;
+}
+
 // Pass 2: the rays queued by k_intersect against the mesh objects.  A mesh hit
 // replaces the recorded hit when it is nearer, or equally near and earlier in
 // the object list - the order Ray::trace's min_by would have seen.
-__global__ void __launch_bounds__(RT_BLOCK) k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
+__global__ void __launch_bounds__(RT_KD_LANES) k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
                                                     const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids)
 {
     __shared__ uint2 kd_stack[DEV_KD_STACK * RT_KD_LANES];
@@ -434,29 +463,84 @@ __global__ void __launch_bounds__(RT_BLOCK) k_mesh(DevScene sc, RayQueue q, cons
             }
         }
         if (!replaced) continue;
-        const DevObject &ob = sc.objects[best_obj];
-        const DevLeaf &F = sc.leaves[ob.frame];
-        const DevMesh &m = sc.meshes[ob.mesh0 + (best_aux >> 24)];
-        LeafRay ry = to_leaf(F, o, d);
-        uint32_t tri = best_aux & 0xFFFFFFu;
-        double tt = 0.0, u = 0.0, v = 0.0;
-        tri_hit(sc.tris + ((size_t)m.tri0 + tri) * 9, ry.o, ry.d, tt, u, v);
-        const uint32_t *tn = sc.tri_n + ((size_t)m.tri0 + tri) * 3;
-        const double *nb = sc.normals + (size_t)m.normal0 * 3;
-        d3 n0 = mk3(nb[3 * tn[0]], nb[3 * tn[0] + 1], nb[3 * tn[0] + 2]);
-        d3 n1 = mk3(nb[3 * tn[1]], nb[3 * tn[1] + 1], nb[3 * tn[1] + 2]);
-        d3 n2 = mk3(nb[3 * tn[2]], nb[3 * tn[2] + 1], nb[3 * tn[2] + 2]);
-        // mesh.rs:102-106
-        d3 nl = m.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
-        d3 n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
-        hit.t[i] = best_t;
-        hit.n[0][i] = n.x;
-        hit.n[1][i] = n.y;
-        hit.n[2][i] = n.z;
-        hit.uv[0][i] = u;
-        hit.uv[1][i] = v;
-        hit.obj[i] = best_obj;
-        if (primary_ids) primary_ids[q.slot[i]] = best_obj;
+        write_mesh_hit(sc, q, hit, primary_ids, i, o, d, best_t, best_obj, best_aux);
+    }
+}
+
+// The same merge for a short queue: one wave per ray, every lane testing its share of the
+// triangles (the reference's brute force, mesh.rs:54-64, spread over 64 lanes), then a
+// wave-wide lexicographic min over (t, triangle index).  A lone wave needs ~100 dependent
+// kd-tree steps at memory latency; 36 independent triangle tests per lane finish in a few
+// microseconds, which is what the late, nearly empty bounce passes are made of.
+RT_DEV void wave_min_hit(double &t, uint32_t &tri)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ot = __shfl_xor(t, off);
+        uint32_t oi = __shfl_xor(tri, off);
+        if (ot < t || (ot == t && oi < tri)) {
+            t = ot;
+            tri = oi;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
+                                                          const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids)
+{
+    const uint32_t count = *mesh_count;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = lane_id();
+    for (uint32_t j = wave; j < count; j += n_waves) {
+        const uint32_t i = mesh_queue[j];
+        d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+        int best_obj = hit.obj[i];
+        double best_t = best_obj >= 0 ? hit.t[i] : DBL_MAX;
+        uint32_t best_aux = 0u;
+        bool replaced = false;
+        for (int k = 0; k < sc.n_objects; ++k) {
+            const DevObject &ob = sc.objects[k];
+            if (ob.kind != DO_MESH) continue;
+            const DevLeaf &F = sc.leaves[ob.frame];
+            LeafRay ry = to_leaf(F, o, d);
+            d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
+            double obj_t = 0.0;
+            uint32_t obj_aux = 0u;
+            bool obj_found = false;
+            for (int mi = 0; mi < ob.n_meshes; ++mi) {
+                const DevMesh &m = sc.meshes[ob.mesh0 + mi];
+                if (!mesh_box_hit(m, ry.o, inv)) continue;
+                const double *__restrict__ tris = sc.tris + (size_t)m.tri0 * 9;
+                double lt = 1.0e300;
+                uint32_t ltri = 0xFFFFFFFFu;
+                for (uint32_t ti = lane; ti < m.n_tris; ti += 64u) {
+                    double t, u, v;
+                    if (tri_hit(tris + (size_t)ti * 9, ry.o, ry.d, t, u, v) && t < lt) {
+                        lt = t; // ti grows within a lane: the first of equal t's is the lowest index
+                        ltri = ti;
+                    }
+                }
+                wave_min_hit(lt, ltri);
+                if (ltri != 0xFFFFFFFFu && (!obj_found || lt < obj_t)) { // min_by keeps the first minimum
+                    obj_t = lt;
+                    obj_aux = ((uint32_t)mi << 24) | (ltri & 0xFFFFFFu);
+                    obj_found = true;
+                }
+            }
+            if (obj_found) {
+                double tw = leaf_t_to_world(F, o, ry, obj_t);
+                if (tw >= 0.0 && tw < DBL_MAX && (best_obj < 0 || tw < best_t || (tw == best_t && k < best_obj))) {
+                    best_t = tw;
+                    best_obj = k;
+                    best_aux = obj_aux;
+                    replaced = true;
+                }
+            }
+        }
+        if (!replaced || lane != 0) continue;
+        write_mesh_hit(sc, q, hit, primary_ids, i, o, d, best_t, best_obj, best_aux);
     }
 }
 
@@ -715,13 +799,14 @@ struct rt_scene {
     RayQueue q[2];
     HitBuf hit;
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
+    uint64_t n_mesh_tris = 0;
     uint32_t *mesh_queue = nullptr; // ray indices that need the kd-trees this pass
     uint32_t *d_counts = nullptr; // 2 x (max_depth + 2): live rays per depth, then mesh-queue lengths per depth
     uint32_t counts_cap = 0;
     uint32_t *d_guards = nullptr; // 6
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr}; // per-kernel timing inside a pass
+    std::vector<hipEvent_t> evp; // per-pass timing events: [0] before raygen, then 3 per depth
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -783,10 +868,14 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         s->counts_cap = max_depth + 2;
     }
     if (!s->d_guards) HIP_TRY(hipMalloc((void **)&s->d_guards, 8 * sizeof(uint32_t)));
+    while (s->evp.size() < 1 + 3 * (size_t)max_depth) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->evp.push_back(e);
+    }
     if (!s->ev0) {
         HIP_TRY(hipEventCreate(&s->ev0));
         HIP_TRY(hipEventCreate(&s->ev1));
-        for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreate(&s->evk[k]));
     }
     return RT_OK;
 }
@@ -825,6 +914,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     if ((rc = upload(s, flat.kd, &s->dev.kd))) return fail(rc);
     if ((rc = upload(s, flat.kd_index, &s->dev.kd_index))) return fail(rc);
     if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
+    if ((rc = upload(s, flat.leaf_tris, &s->dev.leaf_tris))) return fail(rc);
     if ((rc = upload(s, flat.tri_n, &s->dev.tri_n))) return fail(rc);
     if ((rc = upload(s, flat.normals, &s->dev.normals))) return fail(rc);
     if ((rc = upload(s, flat.materials, &s->dev.materials))) return fail(rc);
@@ -838,6 +928,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     }
     for (const DevLeaf &L : flat.leaves)
         if (L.kind == DL_TORUS) s->has_torus = true;
+    for (const DevMesh &m : flat.meshes) s->n_mesh_tris += m.n_tris;
     for (int k = 0; k < 3; ++k) s->dev.background[k] = flat.background[k];
     s->dev.cam_fov_factor = flat.cam_fov_factor;
     std::memcpy(s->dev.cam_c2w, flat.cam_c2w, sizeof(flat.cam_c2w));
@@ -856,8 +947,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    for (int k = 0; k < 4; ++k)
-        if (s->evk[k]) (void)hipEventDestroy(s->evk[k]);
+    for (hipEvent_t e : s->evp) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -895,6 +985,8 @@ static int check_options(const rt_options *o)
     return RT_OK;
 }
 
+#define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
+
 // nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the kd-tree pass
 static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
                              uint32_t *mesh_count, const PassParams &pp, int32_t *ids)
@@ -915,8 +1007,21 @@ static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const R
     default: LAUNCH_I(true, true, true); break;
     }
 #undef LAUNCH_I
-    if (s->has_mesh)
-        hipLaunchKernelGGL(k_mesh, grid, block, 0, st, s->dev, q, s->mesh_queue, mesh_count, s->hit, ids);
+    if (s->has_mesh) {
+        // short queues: one wave per ray over all triangles; long queues: one lane per ray down the kd-tree
+        if ((uint64_t)live * s->n_mesh_tris <= (uint64_t)RT_BRUTE_MAX_TESTS) {
+            uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), block, 0, st, s->dev, q, s->mesh_queue, mesh_count,
+                               s->hit, ids);
+        } else {
+            uint64_t mb = ((uint64_t)live + RT_KD_LANES - 1) / RT_KD_LANES;
+            if (mb > 256 * 16) mb = 256 * 16;
+            hipLaunchKernelGGL(k_mesh, dim3((uint32_t)mb), dim3(RT_KD_LANES), 0, st, s->dev, q, s->mesh_queue, mesh_count,
+                               s->hit, ids);
+        }
+    }
 }
 
 typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
@@ -978,49 +1083,55 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
             } else {
                 HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * (opts->max_depth + 2) * sizeof(uint32_t), st));
                 RT_TRACE("launching raygen grid %u", grid_for(n_slots));
-                HIP_TRY(hipEventRecord(s->evk[3], st));
+                HIP_TRY(hipEventRecord(s->evp[0], st));
                 hipLaunchKernelGGL(k_raygen, dim3(grid_for_wide(n_slots)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, g, rank, n_slots,
                                    s_i, s_j, recip, pp, s->q[0], s->d_counts);
-                RT_TRACE("raygen launched");
-                uint32_t live = n_slots; // upper bound until read back
+                // `live` bounds the rays of the next pass from above: exact right after a read-back,
+                // otherwise the last known value (the count never grows).  The kernels read the true
+                // count on the device; the bound only sizes grids.  Read-backs cost a stream
+                // synchronisation, so after the first bounces they come every fourth pass.
+                uint32_t live = n_slots;
                 int cur = 0;
+                uint32_t passes = 0;
                 for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
-                    HIP_TRY(hipEventRecord(s->evk[0], st));
+                    HIP_TRY(hipEventRecord(s->evp[1 + 3 * depth], st));
                     launch_intersect(s, st, live, s->q[cur], s->d_counts + depth,
                                      s->d_counts + (opts->max_depth + 2) + depth, pp, ids);
-                    HIP_TRY(hipEventRecord(s->evk[1], st));
+                    HIP_TRY(hipEventRecord(s->evp[2 + 3 * depth], st));
                     hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, s->q[cur],
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
-                    HIP_TRY(hipEventRecord(s->evk[2], st));
+                    HIP_TRY(hipEventRecord(s->evp[3 + 3 * depth], st));
                     local.bounce_passes++;
+                    ++passes;
                     cur = 1 - cur;
-                    // learn how many paths survived: sizes the next launch and ends the loop
-                    HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts + depth + 1, sizeof(uint32_t),
-                                           hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    live = s->h_pinned[0];
-                    RT_TRACE("depth %u live %u", depth, live);
-                    {
-                        float ms_k = 0.f;
-                        if (depth == 0) {
-                            HIP_TRY(hipEventElapsedTime(&ms_k, s->evk[3], s->evk[0]));
-                            local.ms_raygen += ms_k;
-                        }
-                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evk[0], s->evk[1]));
-                        local.ms_intersect += ms_k;
-                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evk[1], s->evk[2]));
-                        local.ms_shade += ms_k;
-                        local.n_intersect_launches++;
+                    if (depth < 3 || (depth & 3u) == 3u || depth + 1 == opts->max_depth) {
+                        HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts + depth + 1, sizeof(uint32_t),
+                                               hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        live = s->h_pinned[0];
+                        RT_TRACE("depth %u live %u", depth, live);
+                        if (live == 0) break;
                     }
-                    if (live == 0) break;
                 }
                 HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (opts->max_depth + 1) * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 local.primary_rays += s->h_pinned[0];
                 for (uint32_t k = 0; k < opts->max_depth; ++k) local.rays += s->h_pinned[k];
+                {
+                    float ms_k = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[0], s->evp[1]));
+                    local.ms_raygen += ms_k;
+                    for (uint32_t k = 0; k < passes; ++k) {
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[1 + 3 * k], s->evp[2 + 3 * k]));
+                        local.ms_intersect += ms_k;
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[2 + 3 * k], s->evp[3 + 3 * k]));
+                        local.ms_shade += ms_k;
+                        if (s->h_pinned[k]) local.n_intersect_launches++; // passes that had rays
+                    }
+                }
             }
             HIP_TRY(hipGetLastError());
             ++done;
@@ -1045,8 +1156,11 @@ finished:
         (void)hipMemcpyFromSymbol(&tr, HIP_SYMBOL(g_kd_tris), 8);
         (void)hipMemcpyFromSymbol(&ry, HIP_SYMBOL(g_kd_rays), 8);
         (void)hipMemcpyFromSymbol(&mx, HIP_SYMBOL(g_kd_max), 4);
-        fprintf(stderr, "[kd] traversals %llu  steps/ray %.1f  tris/ray %.1f  max steps %u\n", ry, ry ? (double)it / ry : 0.0,
-                ry ? (double)tr / ry : 0.0, mx);
+        unsigned long long cy = 0, mc = 0;
+        (void)hipMemcpyFromSymbol(&cy, HIP_SYMBOL(g_kd_cyc), 8);
+        (void)hipMemcpyFromSymbol(&mc, HIP_SYMBOL(g_kd_maxcyc), 8);
+        fprintf(stderr, "[kd] traversals %llu  steps/ray %.1f  tris/ray %.1f  max steps %u  cycles/ray %.0f  max cycles %llu\n", ry,
+                ry ? (double)it / ry : 0.0, ry ? (double)tr / ry : 0.0, mx, ry ? (double)cy / ry : 0.0, mc);
     }
 #endif
     float ms = 0.f;
