@@ -674,9 +674,8 @@ __device__ __noinline__ bool csg_eval(const DevScene &sc, const DevObject &ob, d
 
 // ---------------------------------------------------------------------------
 // Meshes.  mesh.rs:66-113 for one triangle record (v0, v0v1, v0v2).
-RT_DEV bool tri_hit(const double *__restrict__ tr, d3 o, d3 d, double &t, double &u, double &v)
+RT_DEV bool tri_hit_v(d3 v0, d3 e1, d3 e2, d3 o, d3 d, double &t, double &u, double &v)
 {
-    d3 v0 = mk3(tr[0], tr[1], tr[2]), e1 = mk3(tr[3], tr[4], tr[5]), e2 = mk3(tr[6], tr[7], tr[8]);
     d3 pvec = cross3(d, e2);
     double det = dot3(e1, pvec);
     if (det < 2.220446049250313e-16) return false; // f64::EPSILON: back faces and edge-on triangles
@@ -703,6 +702,11 @@ RT_DEV bool tri_hit(const double *__restrict__ tr, d3 o, d3 d, double &t, double
     return true;
 }
 
+RT_DEV bool tri_hit(const double *__restrict__ tr, d3 o, d3 d, double &t, double &u, double &v)
+{
+    return tri_hit_v(mk3(tr[0], tr[1], tr[2]), mk3(tr[3], tr[4], tr[5]), mk3(tr[6], tr[7], tr[8]), o, d, t, u, v);
+}
+
 // bounding_box.rs:13-44 against the Mesh::new box (which contains the origin)
 RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
 {
@@ -721,124 +725,30 @@ RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
 }
 
 // Nearest triangle (smallest t, lowest index on ties) = element 0 of the
-// reference's stable sort over all triangle hits (mesh.rs:54-64).
-//
-// Stack-based kd-tree walk, front to back.  The deferred far children live in
-// LDS, one 8-byte entry per level: (node, far bound of that cell as an f32
-// rounded up).  Cells are visited in ray order, so the near bound of a popped
-// cell is the far bound of the leaf just finished and need not be stored.
-// `stk` points at this lane's column: entry e is stk[e * RT_KD_LANES].
-#define RT_KD_LANES 128 // = threads per k_mesh workgroup
-#ifdef RT_KD_STATS
-__device__ unsigned long long g_kd_iters, g_kd_tris, g_kd_rays;
-__device__ unsigned int g_kd_max;
-__device__ unsigned long long g_kd_cyc, g_kd_maxcyc, g_kd_maxcyc_steps;
-#endif
-RT_DEV bool mesh_nearest(const DevScene &sc, const DevMesh &m, d3 o, d3 d, d3 inv, uint2 *stk, double &best_t,
-                         uint32_t &best_tri)
-{
-#ifdef RT_KD_STATS
-    unsigned int st_iters = 0, st_tris = 0;
-    long long st_t0 = clock64();
-#endif
-    // clip the ray against the tight (padded) bounds
-    double t0 = 0.0, t1 = 1.0e300;
-    {
-        double lo, hi;
-        lo = (m.bmin[0] - o.x) * inv.x;
-        hi = (m.bmax[0] - o.x) * inv.x;
-        if (lo > hi) { double s = lo; lo = hi; hi = s; }
-        if (lo == lo && lo > t0) t0 = lo;
-        if (hi == hi && hi < t1) t1 = hi;
-        lo = (m.bmin[1] - o.y) * inv.y;
-        hi = (m.bmax[1] - o.y) * inv.y;
-        if (lo > hi) { double s = lo; lo = hi; hi = s; }
-        if (lo == lo && lo > t0) t0 = lo;
-        if (hi == hi && hi < t1) t1 = hi;
-        lo = (m.bmin[2] - o.z) * inv.z;
-        hi = (m.bmax[2] - o.z) * inv.z;
-        if (lo > hi) { double s = lo; lo = hi; hi = s; }
-        if (lo == lo && lo > t0) t0 = lo;
-        if (hi == hi && hi < t1) t1 = hi;
-    }
-    if (t0 > t1) return false;
-    bool found = false;
-    best_t = 1.0e300;
-    best_tri = 0xFFFFFFFFu;
+// reference's stable sort over all triangle hits (mesh.rs:54-64).  The walk
+// through the mesh's grid lives in k_mesh (rt_kernels.hip).
+#define RT_MESH_LANES 256 // = threads per k_mesh workgroup
 
-    int sp = 0;
-    uint32_t node = 0;
-    double tmin = t0, tmax = t1;
-    const uint4 *__restrict__ kd = reinterpret_cast<const uint4 *>(sc.kd + m.kd0); // one 16-byte load per node
-    const double *__restrict__ leaf_tris = sc.leaf_tris + (size_t)m.kd_index0 * 10;
-    // "while-while": all lanes first walk down to their next leaf (cheap steps), then the wave
-    // tests triangles together (the expensive part), instead of paying for both in every step.
-    for (int round = 0; round < 4096; ++round) { // bounded: every round consumes one leaf
-        uint4 raw = kd[node];
-        for (int step = 0; step < 64 && (raw.z & 3u) != 3u; ++step) { // depth <= DEV_KD_STACK
-#ifdef RT_KD_STATS
-            ++st_iters;
-#endif
-            const uint32_t axis = raw.z & 3u, right = raw.z >> 2;
-            const double split = __hiloint2double((int)raw.y, (int)raw.x);
-            double oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
-            double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
-            double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-            double tplane = (split - oa) * ia;
-            bool below_first = (oa < split) || (oa == split && da <= 0.0);
-            uint32_t first = below_first ? node + 1u : right;
-            uint32_t second = below_first ? right : node + 1u;
-            // slack: a hit within rounding distance of the plane is searched on both sides
-            double eps = 1e-9 * (fabs(tplane) + 1.0);
-            if (tplane > tmax + eps || tplane <= 0.0) {
-                node = first;
-            } else if (tplane < tmin - eps) {
-                node = second;
-            } else {
-                if (sp < DEV_KD_STACK) {
-                    stk[sp * RT_KD_LANES] = make_uint2(second, __float_as_uint(__double2float_ru(tmax)));
-                    ++sp;
-                }
-                node = first;
-                tmax = tplane + eps;
-            }
-            raw = kd[node];
-        }
-        if ((raw.z & 3u) == 3u) {
-            const uint32_t first = raw.z >> 2, cnt = raw.w;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const double *__restrict__ rec = leaf_tris + (size_t)(first + k) * 10;
-                const uint32_t ti = (uint32_t)__double2loint(rec[9]);
-                double t, u, v;
-#ifdef RT_KD_STATS
-                ++st_tris;
-#endif
-                if (tri_hit(rec, o, d, t, u, v)) {
-                    if (t < best_t || (t == best_t && ti < best_tri)) {
-                        best_t = t;
-                        best_tri = ti;
-                        found = true;
-                    }
-                }
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        uint2 e = stk[sp * RT_KD_LANES];
-        node = e.x;
-        // the stored bounds are f32 round-ups: step back by more than that rounding
-        tmin = tmax - (2.4e-7 * fabs(tmax) + 1e-9);
-        tmax = (double)__uint_as_float(e.y);
-        if (best_t < tmin) break; // every remaining cell lies beyond the hit
-    }
-#ifdef RT_KD_STATS
-    atomicAdd(&g_kd_iters, (unsigned long long)st_iters);
-    atomicAdd(&g_kd_tris, (unsigned long long)st_tris);
-    atomicAdd(&g_kd_rays, 1ull);
-    atomicMax(&g_kd_max, st_iters);
-    unsigned long long cyc = (unsigned long long)(clock64() - st_t0);
-    atomicAdd(&g_kd_cyc, cyc);
-    atomicMax(&g_kd_maxcyc, cyc);
-#endif
-    return found;
+// clip the ray against the tight (padded) bounds of the mesh
+RT_DEV bool mesh_clip(const DevMesh &m, d3 o, d3 inv, double &t0, double &t1)
+{
+    t0 = 0.0;
+    t1 = 1.0e300;
+    double lo, hi;
+    lo = (m.bmin[0] - o.x) * inv.x;
+    hi = (m.bmax[0] - o.x) * inv.x;
+    if (lo > hi) { double s = lo; lo = hi; hi = s; }
+    if (lo == lo && lo > t0) t0 = lo;
+    if (hi == hi && hi < t1) t1 = hi;
+    lo = (m.bmin[1] - o.y) * inv.y;
+    hi = (m.bmax[1] - o.y) * inv.y;
+    if (lo > hi) { double s = lo; lo = hi; hi = s; }
+    if (lo == lo && lo > t0) t0 = lo;
+    if (hi == hi && hi < t1) t1 = hi;
+    lo = (m.bmin[2] - o.z) * inv.z;
+    hi = (m.bmax[2] - o.z) * inv.z;
+    if (lo > hi) { double s = lo; lo = hi; hi = s; }
+    if (lo == lo && lo > t0) t0 = lo;
+    if (hi == hi && hi < t1) t1 = hi;
+    return !(t0 > t1);
 }

@@ -77,23 +77,29 @@ struct DevObject {
     double density;
 };
 
-// 16-byte kd-tree node.  Interior: a = (right child << 2) | axis, the left
-// child is the next node.  Leaf: a = (first entry in tri index list << 2) | 3,
-// b = triangle count.
-struct DevKdNode {
-    double split;
-    uint32_t a;
-    uint32_t b;
-};
-
+// One uniform grid per mesh.  The reference tests every triangle of a mesh
+// (mesh.rs:54-64); the grid only decides which triangles a ray visits.
+//  - occupancy words, one per 32 cells, x fastest: (bits, rank of the word's first
+//    cell among the mesh's occupied cells).  The k_mesh workgroups keep them in
+//    LDS, so stepping through empty space never leaves the CU;
+//  - distance nibbles, one per cell: Chebyshev distance in cells to the nearest
+//    occupied cell, capped at 15.  From a cell at distance k a ray may move k-1
+//    cells along any axis without meeting a triangle, so open space costs a few
+//    jumps instead of one step per cell.  Also in LDS;
+//  - cell_start[rank] .. cell_start[rank+1]: the occupied cell's run of 80-byte
+//    triangle records in `cell_tris` (v0, e1, e2, triangle index), ascending
+//    index.  Also kept in LDS while all meshes' entries fit DEV_GRID_MAX_STARTS.
 struct DevMesh {
     uint32_t tri0, n_tris;   // into tri data (72 B records: v0, e1, e2) and tri_n
     uint32_t normal0;        // into normals
-    uint32_t kd0;            // root node
-    uint32_t kd_index0;      // base of this mesh's triangle index list
     uint32_t smooth;
+    uint32_t n[3];           // cells along x, y, z (each <= 255)
+    uint32_t bits0;          // first (bits, rank) pair of this mesh in grid_bits
+    uint32_t cell0;          // first entry of this mesh's cell_start run (occupied cells + 1 entries)
+    uint32_t dist0;          // first word of this mesh's distance nibbles in grid_dist
     double qmin[3], qmax[3]; // Mesh::new bounds, which include the origin (mesh.rs:32-42)
-    double bmin[3], bmax[3]; // tight bounds for the kd-tree traversal
+    double bmin[3], bmax[3]; // grid bounds: the tight bounds of the triangles, padded
+    double cell[3], inv_cell[3];
 };
 
 struct DevMaterial {
@@ -114,17 +120,20 @@ struct DevScene {
     const DevLeaf *leaves;
     const int32_t *prog;
     const DevMesh *meshes;
-    const DevKdNode *kd;
-    const uint32_t *kd_index;
-    const double *tris;    // 9 per triangle
-    const double *leaf_tris; // 10 per kd leaf reference, in leaf order: the 9 above + the triangle index (low word)
+    const uint32_t *grid_bits;  // (bits, rank) pairs of every mesh grid, concatenated
+    const uint32_t *grid_dist;  // distance nibbles of every mesh grid, 8 cells per word
+    const uint32_t *cell_start; // per mesh: occupied cells + 1 offsets into cell_tris (absolute record indices)
+    const double *tris;      // 9 per triangle
+    const double *cell_tris; // 10 per (cell, triangle) reference, in cell order: the 9 above + the triangle index (low word)
     const uint32_t *tri_n; // 3 per triangle (normal indices, mesh-relative)
     const double *normals; // xyz
     const DevMaterial *materials;
     const DevTexture *textures;
     const uint8_t *image_data;
     int32_t n_objects;
-    int32_t pad;
+    uint32_t n_grid_words; // (bits, rank) pairs in grid_bits
+    uint32_t n_cell_starts; // entries in cell_start
+    uint32_t n_dist_words;  // words in grid_dist
     double background[3];
     double cam_fov_factor;
     double cam_c2w[16];
@@ -133,4 +142,6 @@ struct DevScene {
 #define DEV_MAX_LEAVES_PER_OBJECT 256
 #define DEV_MAX_INTERVALS 6   // per list
 #define DEV_CSG_STACK 4       // lists alive at once
-#define DEV_KD_STACK 20       // kd-tree depth limit = LDS stack entries per lane
+#define DEV_GRID_MAX_WORDS 2048 // occupancy words of all meshes together: 16 KB of LDS with their ranks, 32 KB of distances
+#define DEV_GRID_MAX_STARTS 6144 // cell_start entries kept in LDS (24 KB); beyond that they are read from memory
+#define DEV_GRID_MAX_AXIS 255

@@ -1,10 +1,10 @@
 // rt_flatten.cpp — rt_scene_desc -> device layout (rt_device.h): composes the
 // per-node transforms along every root-to-primitive path, turns CSG trees into
 // postfix programs, pre-computes the rectangle bounds the reference computes in
-// its constructors, and builds one kd-tree per mesh.
+// its constructors, and builds one uniform grid per mesh.
 //
-// The kd-tree is new: the reference tests every triangle of a mesh and sorts
-// the hits (mesh.rs:54-64).  The tree only decides which triangles a ray
+// The grid is new: the reference tests every triangle of a mesh and sorts
+// the hits (mesh.rs:54-64).  The grid only decides which triangles a ray
 // visits; the triangle test and the "nearest t, lowest index on ties" choice
 // are the reference's, so the result equals the brute-force one.
 #include "rt_flatten.h"
@@ -49,191 +49,46 @@ bool linear_part_is_identity(const Mat4 &a)
     return true;
 }
 
-// ---------------------------------------------------------------- kd-tree
+// ---------------------------------------------------------------- mesh grids
 struct Box {
     double lo[3], hi[3];
 };
 
-// One reference to a triangle inside a cell: the triangle and the bounds of the
-// part of it that lies in the cell ("split clipping": without it the diagonal,
-// chunky triangles of LinkedTorus.obj end up in ten leaves each and no empty
-// space is ever cut away).
-struct KdRef {
-    uint32_t tri;
-    Box box;
-};
-
-} }
-int g_kd_reason[4];
-namespace rt_host { namespace {
-
-struct KdBuilder {
-    const std::vector<double> &verts; // 9 per triangle: v0, v1, v2 (absolute)
-    std::vector<DevKdNode> &nodes;
-    std::vector<uint32_t> &index;
-    uint32_t index_base; // start of this mesh's index list
-    int max_depth;
-    double pad;
-    double kIsect = 20.0, kTrav = 15.0, kEmptyBonus = 0.5; // chosen by measurement on MI355X
-    size_t leaf_max = 1;
-    double min_empty = 0.1;
-
-    // bounds of (triangle clipped to `cell` grown by pad); false if nothing is left
-    bool clip(uint32_t tri, const Box &cell, Box &out) const
-    {
-        double poly[16][3], tmp[16][3];
-        int n = 3;
-        for (int v = 0; v < 3; ++v)
-            for (int k = 0; k < 3; ++k) poly[v][k] = verts[(size_t)tri * 9 + v * 3 + k];
-        for (int axis = 0; axis < 3 && n > 0; ++axis) {
-            for (int side = 0; side < 2 && n > 0; ++side) {
-                const double plane = side == 0 ? cell.lo[axis] - pad : cell.hi[axis] + pad;
-                int m = 0;
-                for (int i = 0; i < n; ++i) {
-                    const double *a = poly[i], *b = poly[(i + 1) % n];
-                    bool ina = side == 0 ? a[axis] >= plane : a[axis] <= plane;
-                    bool inb = side == 0 ? b[axis] >= plane : b[axis] <= plane;
-                    if (ina) {
-                        for (int k = 0; k < 3; ++k) tmp[m][k] = a[k];
-                        ++m;
-                    }
-                    if (ina != inb) {
-                        double t = (plane - a[axis]) / (b[axis] - a[axis]);
-                        for (int k = 0; k < 3; ++k) tmp[m][k] = a[k] + t * (b[k] - a[k]);
-                        tmp[m][axis] = plane;
-                        ++m;
-                    }
+// Does triangle `v` (9 doubles: three vertices) touch `cell` grown by `pad`?
+// Sutherland-Hodgman clipping of the triangle against the six planes; what is
+// left is empty exactly when the triangle misses the grown box.
+bool tri_touches_box(const double *v, const Box &cell, double pad)
+{
+    double poly[16][3], tmp[16][3];
+    int n = 3;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) poly[i][k] = v[i * 3 + k];
+    for (int axis = 0; axis < 3 && n > 0; ++axis) {
+        for (int side = 0; side < 2 && n > 0; ++side) {
+            const double plane = side == 0 ? cell.lo[axis] - pad : cell.hi[axis] + pad;
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const double *a = poly[i], *b = poly[(i + 1) % n];
+                bool ina = side == 0 ? a[axis] >= plane : a[axis] <= plane;
+                bool inb = side == 0 ? b[axis] >= plane : b[axis] <= plane;
+                if (ina) {
+                    for (int k = 0; k < 3; ++k) tmp[m][k] = a[k];
+                    ++m;
                 }
-                n = m;
-                for (int i = 0; i < n; ++i)
-                    for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
-            }
-        }
-        if (n == 0) return false;
-        for (int k = 0; k < 3; ++k) {
-            out.lo[k] = poly[0][k];
-            out.hi[k] = poly[0][k];
-        }
-        for (int i = 1; i < n; ++i)
-            for (int k = 0; k < 3; ++k) {
-                out.lo[k] = std::fmin(out.lo[k], poly[i][k]);
-                out.hi[k] = std::fmax(out.hi[k], poly[i][k]);
-            }
-        for (int k = 0; k < 3; ++k) {
-            out.lo[k] -= pad;
-            out.hi[k] += pad;
-        }
-        return true;
-    }
-
-    void make_leaf(const std::vector<KdRef> &prims)
-    {
-        DevKdNode n;
-        n.split = 0.0;
-        n.a = (uint32_t)(((index.size() - index_base) << 2) | 3u);
-        n.b = (uint32_t)prims.size();
-        std::vector<uint32_t> sorted;
-        for (const KdRef &r : prims) sorted.push_back(r.tri);
-        std::sort(sorted.begin(), sorted.end());
-        index.insert(index.end(), sorted.begin(), sorted.end());
-        nodes.push_back(n);
-    }
-
-    void build(const std::vector<KdRef> &prims, const Box &box, int depth, int bad)
-    {
-        if (prims.size() <= leaf_max || depth >= max_depth) {
-            g_kd_reason[prims.size() <= leaf_max ? 0 : 1]++;
-            make_leaf(prims);
-            return;
-        }
-        double d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
-        double total_sa = 2.0 * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2]);
-        double inv_sa = total_sa > 0.0 ? 1.0 / total_sa : 0.0;
-        double old_cost = kIsect * (double)prims.size();
-        double best_cost = std::numeric_limits<double>::infinity();
-        int best_axis = -1;
-        double best_split = 0.0;
-
-        struct Edge {
-            double t;
-            bool start;
-        };
-        std::vector<Edge> edges(prims.size() * 2);
-        for (int axis = 0; axis < 3; ++axis) {
-            for (size_t i = 0; i < prims.size(); ++i) {
-                edges[2 * i] = Edge{std::fmax(prims[i].box.lo[axis], box.lo[axis]), true};
-                edges[2 * i + 1] = Edge{std::fmin(prims[i].box.hi[axis], box.hi[axis]), false};
-            }
-            std::sort(edges.begin(), edges.end(), [](const Edge &a, const Edge &b) {
-                if (a.t == b.t) return (int)a.start > (int)b.start;
-                return a.t < b.t;
-            });
-            size_t n_below = 0, n_above = prims.size();
-            int o0 = (axis + 1) % 3, o1 = (axis + 2) % 3;
-            for (size_t i = 0; i < edges.size(); ++i) {
-                if (!edges[i].start) --n_above;
-                double t = edges[i].t;
-                if (t > box.lo[axis] && t < box.hi[axis]) {
-                    double below_sa = 2.0 * (d[o0] * d[o1] + (t - box.lo[axis]) * (d[o0] + d[o1]));
-                    double above_sa = 2.0 * (d[o0] * d[o1] + (box.hi[axis] - t) * (d[o0] + d[o1]));
-                    // the bonus for cutting away empty space applies only to a worthwhile slab:
-                    // sliver cuts would otherwise win every time and use up the depth budget
-                    double frac = n_below == 0 ? (t - box.lo[axis]) / d[axis] : (box.hi[axis] - t) / d[axis];
-                    double eb = ((n_above == 0 || n_below == 0) && frac >= min_empty) ? kEmptyBonus : 0.0;
-                    double cost = kTrav + kIsect * (1.0 - eb) *
-                                              (below_sa * inv_sa * (double)n_below + above_sa * inv_sa * (double)n_above);
-                    if (cost < best_cost) {
-                        best_cost = cost;
-                        best_axis = axis;
-                        best_split = t;
-                    }
+                if (ina != inb) {
+                    double t = (plane - a[axis]) / (b[axis] - a[axis]);
+                    for (int k = 0; k < 3; ++k) tmp[m][k] = a[k] + t * (b[k] - a[k]);
+                    tmp[m][axis] = plane;
+                    ++m;
                 }
-                if (edges[i].start) ++n_below;
             }
+            n = m;
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
         }
-        if (best_cost > old_cost) ++bad;
-        if (best_axis < 0 || (best_cost > 4.0 * old_cost && prims.size() < 16) || bad >= 3) {
-            g_kd_reason[2]++;
-            make_leaf(prims);
-            return;
-        }
-        Box bl = box, bh = box;
-        bl.hi[best_axis] = best_split;
-        bh.lo[best_axis] = best_split;
-        std::vector<KdRef> below, above;
-        for (const KdRef &r : prims) {
-            // A reference whose (padded) bounds merely touch the plane stays on its own side:
-            // candidate planes are exactly such bounds, and listing the touching triangle on
-            // both sides would duplicate one reference at every split.
-            bool lo_side = r.box.lo[best_axis] < best_split, hi_side = r.box.hi[best_axis] > best_split;
-            if (!lo_side && !hi_side) lo_side = true; // flat on the plane
-            if (lo_side && hi_side) {
-                KdRef c;
-                c.tri = r.tri;
-                if (clip(r.tri, bl, c.box)) below.push_back(c);
-                if (clip(r.tri, bh, c.box)) above.push_back(c);
-            } else if (lo_side) {
-                below.push_back(r);
-            } else {
-                above.push_back(r);
-            }
-        }
-        if (below.size() == prims.size() && above.size() == prims.size()) {
-            g_kd_reason[3]++;
-            make_leaf(prims);
-            return;
-        }
-        size_t me = nodes.size();
-        DevKdNode n;
-        n.split = best_split;
-        n.a = (uint32_t)best_axis;
-        n.b = 0;
-        nodes.push_back(n);
-        build(below, bl, depth + 1, bad);
-        nodes[me].a = (uint32_t)((nodes.size() << 2) | (uint32_t)best_axis);
-        build(above, bh, depth + 1, bad);
     }
-};
+    return n > 0;
+}
 
 // ---------------------------------------------------------------- flattening
 struct Flattener {
@@ -482,51 +337,129 @@ struct Flattener {
                 dm.bmax[k] = std::fmax(dm.bmax[k], pb[t].hi[k]);
             }
         }
-        // pad every box so that rounding in the traversal cannot step over a triangle
+        // pad the boxes so that rounding in the traversal cannot step over a triangle
         double ext = 0.0;
         for (int k = 0; k < 3; ++k)
             if (m.n_triangles) ext = std::fmax(ext, std::fmax(std::fabs(dm.bmin[k]), std::fabs(dm.bmax[k])));
-        double pad = 1e-9 * (ext > 0.0 ? ext : 1.0);
-        for (auto &b : pb)
-            for (int k = 0; k < 3; ++k) {
-                b.lo[k] -= pad;
-                b.hi[k] += pad;
-            }
-        Box root;
+        const double pad = 1e-9 * (ext > 0.0 ? ext : 1.0);
         for (int k = 0; k < 3; ++k) {
             if (!m.n_triangles) dm.bmin[k] = dm.bmax[k] = 0.0;
             dm.bmin[k] -= 2.0 * pad;
             dm.bmax[k] += 2.0 * pad;
-            root.lo[k] = dm.bmin[k];
-            root.hi[k] = dm.bmax[k];
         }
-        dm.kd0 = (uint32_t)out.kd.size();
-        dm.kd_index0 = (uint32_t)out.kd_index.size();
-        std::vector<DevKdNode> nodes; // mesh-relative node indices
-        int max_depth = (int)std::lround(8.0 + 1.3 * std::log2((double)std::max<uint32_t>(1u, m.n_triangles)));
-        if (max_depth > DEV_KD_STACK - 1) max_depth = DEV_KD_STACK - 1;
-        KdBuilder kb{tri_verts, nodes, out.kd_index, dm.kd_index0, max_depth, pad};
-        if (const char *e = std::getenv("RT_KD_ISECT")) kb.kIsect = std::atof(e);     // tuning knobs, not API
-        if (const char *e = std::getenv("RT_KD_LEAF")) kb.leaf_max = (size_t)std::atoi(e);
-        if (const char *e = std::getenv("RT_KD_EMPTY")) kb.kEmptyBonus = std::atof(e);
-        if (const char *e = std::getenv("RT_KD_TRAV")) kb.kTrav = std::atof(e);
-        if (const char *e = std::getenv("RT_KD_MINEMPTY")) kb.min_empty = std::atof(e);
-        std::vector<KdRef> all(m.n_triangles);
+        // resolution: about `density` cells per triangle, cells as close to cubes as the bounds
+        // allow, and all grids of the scene together within the LDS budget of k_mesh
+        double density = 4.0; // measured on MI355X with LinkedTorus.obj: 2..16 within 5 %, 4 best
+        if (const char *e = std::getenv("RT_GRID_DENSITY")) density = std::atof(e); // tuning knob, not API
+        uint32_t n_mesh_nodes = 0;
+        for (uint32_t i = 0; i < d->n_nodes; ++i) n_mesh_nodes += d->nodes[i].kind == RT_SHAPE_MESH ? 1u : 0u;
+        const double budget = (double)DEV_GRID_MAX_WORDS * 32.0 / (double)std::max<uint32_t>(1u, n_mesh_nodes) - 32.0;
+        if (budget < 1.0) throw Err{RT_ERR_UNSUPPORTED, "too many meshes for the device grid budget"};
+        double target = std::fmin(std::fmax(density * (double)m.n_triangles, 1.0), budget);
+        double e3[3], vol = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            e3[k] = dm.bmax[k] - dm.bmin[k];
+            vol *= e3[k];
+        }
+        const double edge = std::cbrt(vol / target);
+        for (int pass = 0; pass < 64; ++pass) {
+            double cells = 1.0;
+            for (int k = 0; k < 3; ++k) {
+                double nk = std::floor(e3[k] / (edge * std::pow(1.05, pass)) + 0.5);
+                dm.n[k] = (uint32_t)std::fmin(std::fmax(nk, 1.0), (double)DEV_GRID_MAX_AXIS);
+                cells *= (double)dm.n[k];
+            }
+            if (cells <= budget) break; // rounding up on a flat mesh can overshoot the budget: coarsen
+        }
+        const size_t n_cells = (size_t)dm.n[0] * dm.n[1] * dm.n[2];
+        if ((double)n_cells > budget) throw Err{RT_ERR_UNSUPPORTED, "mesh grid does not fit the device budget"};
+        for (int k = 0; k < 3; ++k) {
+            dm.cell[k] = e3[k] / (double)dm.n[k];
+            dm.inv_cell[k] = 1.0 / dm.cell[k];
+        }
+        // triangles per cell: the cells of the triangle's bounding box that the triangle touches
+        std::vector<std::vector<uint32_t>> cells(n_cells);
         for (uint32_t t = 0; t < m.n_triangles; ++t) {
-            all[t].tri = t;
-            all[t].box = pb[t];
+            int lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = (int)std::floor((pb[t].lo[k] - pad - dm.bmin[k]) * dm.inv_cell[k]);
+                hi[k] = (int)std::floor((pb[t].hi[k] + pad - dm.bmin[k]) * dm.inv_cell[k]);
+                lo[k] = std::max(0, std::min(lo[k] - 1, (int)dm.n[k] - 1)); // one cell of margin, then the exact test
+                hi[k] = std::max(0, std::min(hi[k] + 1, (int)dm.n[k] - 1));
+            }
+            for (int z = lo[2]; z <= hi[2]; ++z)
+                for (int y = lo[1]; y <= hi[1]; ++y)
+                    for (int x = lo[0]; x <= hi[0]; ++x) {
+                        Box c;
+                        const int idx[3] = {x, y, z};
+                        for (int k = 0; k < 3; ++k) {
+                            c.lo[k] = dm.bmin[k] + (double)idx[k] * dm.cell[k];
+                            c.hi[k] = dm.bmin[k] + (double)(idx[k] + 1) * dm.cell[k];
+                        }
+                        if (tri_touches_box(&tri_verts[(size_t)t * 9], c, pad))
+                            cells[((size_t)z * dm.n[1] + y) * dm.n[0] + x].push_back(t); // ascending t
+                    }
         }
-        kb.build(all, root, 0, 0);
-        out.kd.insert(out.kd.end(), nodes.begin(), nodes.end());
-        // leaf-ordered copies of the triangle records: a leaf's triangles are then one
-        // contiguous run, with no index indirection in the traversal's dependent-load chain
-        for (size_t e = dm.kd_index0; e < out.kd_index.size(); ++e) {
-            const uint32_t t = out.kd_index[e];
-            for (int k = 0; k < 9; ++k) out.leaf_tris.push_back(out.tris[((size_t)dm.tri0 + t) * 9 + k]);
-            double tag = 0.0;
-            std::memcpy(&tag, &t, sizeof(t));
-            out.leaf_tris.push_back(tag);
+        // occupancy words: (32 cell bits, number of occupied cells of this mesh before the word);
+        // cell_start is indexed by that rank, so only occupied cells take an entry
+        dm.bits0 = (uint32_t)(out.grid_bits.size() / 2);
+        dm.cell0 = (uint32_t)out.cell_start.size();
+        const size_t n_words = (n_cells + 31) / 32;
+        uint32_t rank = 0;
+        for (size_t wd = 0; wd < n_words; ++wd) {
+            uint32_t bits = 0;
+            for (size_t c = wd * 32; c < std::min(n_cells, wd * 32 + 32); ++c)
+                if (!cells[c].empty()) bits |= 1u << (c % 32);
+            out.grid_bits.push_back(bits);
+            out.grid_bits.push_back(rank);
+            rank += (uint32_t)__builtin_popcount(bits);
         }
+        // Chebyshev distance to the nearest occupied cell, by repeated dilation, capped at 15
+        {
+            std::vector<uint8_t> dist(n_cells, 15);
+            for (size_t c = 0; c < n_cells; ++c)
+                if (!cells[c].empty()) dist[c] = 0;
+            const int nx = (int)dm.n[0], ny = (int)dm.n[1], nz = (int)dm.n[2];
+            for (int r = 1; r < 15; ++r) {
+                bool any = false;
+                for (int z = 0; z < nz; ++z)
+                    for (int y = 0; y < ny; ++y)
+                        for (int x = 0; x < nx; ++x) {
+                            const size_t c = ((size_t)z * ny + y) * nx + x;
+                            if (dist[c] != 15) continue;
+                            bool near = false;
+                            for (int dz = -1; dz <= 1 && !near; ++dz)
+                                for (int dy = -1; dy <= 1 && !near; ++dy)
+                                    for (int dx = -1; dx <= 1 && !near; ++dx) {
+                                        int X = x + dx, Y = y + dy, Z = z + dz;
+                                        if (X < 0 || Y < 0 || Z < 0 || X >= nx || Y >= ny || Z >= nz) continue;
+                                        near = dist[((size_t)Z * ny + Y) * nx + X] == r - 1;
+                                    }
+                            if (near) {
+                                dist[c] = (uint8_t)r;
+                                any = true;
+                            }
+                        }
+                if (!any) break;
+            }
+            dm.dist0 = (uint32_t)out.grid_dist.size();
+            out.grid_dist.resize(out.grid_dist.size() + (n_cells + 7) / 8, 0u);
+            for (size_t c = 0; c < n_cells; ++c) out.grid_dist[dm.dist0 + c / 8] |= (uint32_t)dist[c] << (4 * (c % 8));
+        }
+        for (size_t c = 0; c < n_cells; ++c) {
+            if (cells[c].empty()) continue;
+            out.cell_start.push_back((uint32_t)(out.cell_tris.size() / 10));
+            // cell-ordered copies of the triangle records: a cell's triangles are one contiguous
+            // run, with no index indirection in the walk's dependent-load chain
+            for (uint32_t t : cells[c]) {
+                for (int k = 0; k < 9; ++k) out.cell_tris.push_back(out.tris[((size_t)dm.tri0 + t) * 9 + k]);
+                double tag = 0.0;
+                std::memcpy(&tag, &t, sizeof(t));
+                out.cell_tris.push_back(tag);
+            }
+        }
+        out.cell_start.push_back((uint32_t)(out.cell_tris.size() / 10));
+        if (out.grid_bits.size() / 2 > DEV_GRID_MAX_WORDS) throw Err{RT_ERR_UNSUPPORTED, "mesh grids exceed the device budget"};
         out.meshes.push_back(dm);
         ++obj.n_meshes;
     }

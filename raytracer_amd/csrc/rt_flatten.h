@@ -13,10 +13,11 @@ struct FlatScene {
     std::vector<DevLeaf> leaves;
     std::vector<int32_t> prog;
     std::vector<DevMesh> meshes;
-    std::vector<DevKdNode> kd;
-    std::vector<uint32_t> kd_index;
+    std::vector<uint32_t> grid_bits;
+    std::vector<uint32_t> grid_dist;
+    std::vector<uint32_t> cell_start;
     std::vector<double> tris;
-    std::vector<double> leaf_tris;
+    std::vector<double> cell_tris;
     std::vector<uint32_t> tri_n;
     std::vector<double> normals;
     std::vector<DevMaterial> materials;

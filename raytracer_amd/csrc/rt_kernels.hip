@@ -10,8 +10,8 @@
 //                 survivors into the other ray queue       materials/*, texture.rs)
 //
 // Every path advances one segment per pass, so `depth` is a launch constant.
-// Survivors are appended with one atomic per wave (ballot + popcount prefix),
-// which keeps the queues dense as paths die at different depths.  A path
+// Survivors are appended with one atomic per workgroup (ballot + popcount
+// prefix), which keeps the queues dense as paths die at different depths.  A path
 // contributes to its pixel exactly once, when it ends:
 //   colour = a_0 * a_1 * ... * a_{k-1} * X,   X = background            (miss, depth cap)
 //                                             X = emit + background     (light)
@@ -52,6 +52,11 @@ struct HitBuf {
     int32_t *obj;
 };
 
+#ifndef RT_MESH_WAVES
+#define RT_MESH_WAVES 3
+#endif
+#define RT_MESH_OCC __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, RT_MESH_WAVES)))
+
 struct PassParams {
     uint64_t seed;
     uint32_t stratum;
@@ -64,19 +69,6 @@ struct PassParams {
 #define RT_BLOCK 256
 
 RT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// Append with one atomic per wave.  Called by every lane of the wave.
-RT_DEV uint32_t wave_append(bool alive, uint32_t *counter)
-{
-    unsigned long long mask = __ballot(alive);
-    uint32_t base = 0;
-    if (mask != 0ull) {
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-    }
-    return base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
-}
 
 // Append with one atomic per workgroup: a single counter word takes about 90 atomics per
 // microsecond on this chip, so a per-wave atomic caps a pass at ~6 G appended rays/s; with
@@ -230,47 +222,22 @@ __device__ __noinline__ Candidate eval_csg_object(const DevScene &sc, const DevO
     return pick_from_list(res, ob.mode);
 }
 
-// Composite::intersect over Mesh children (composite.rs:20-34, mesh.rs:116-128).
-// `stk`: this lane's kd stack column in LDS.
-RT_DEV Candidate eval_mesh_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, uint2 *stk)
+// Does the ray need the walk through a mesh of this object?  It must pass the Mesh::new box
+// (mesh.rs:32-42,117: no box hit, no intersection) and enter the triangles' own bounds before
+// the nearest hit found among the other objects (`have_hit`, `best_t`; slack keeps ties in play).
+RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 d, bool have_hit, double best_t)
 {
-    Candidate c;
-    c.ok = false;
-    c.t = 0.0;
-    c.aux = 0u;
     const DevLeaf &F = sc.leaves[ob.frame];
     LeafRay ry = to_leaf(F, o, d);
     d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
-    double best = 0.0;
-    bool found = false;
+    const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d));
+    const double bound = have_hit ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
+    bool any = false;
     for (int mi = 0; mi < ob.n_meshes; ++mi) {
         const DevMesh &m = sc.meshes[ob.mesh0 + mi];
-        if (!mesh_box_hit(m, ry.o, inv)) continue;
-        double t;
-        uint32_t tri;
-        if (mesh_nearest(sc, m, ry.o, ry.d, inv, stk, t, tri)) {
-            if (!found || t < best) { // min_by keeps the first minimum
-                best = t;
-                c.aux = ((uint32_t)mi << 24) | (tri & 0xFFFFFFu);
-                found = true;
-            }
-        }
+        double t0, t1;
+        any = any || (mesh_box_hit(m, ry.o, inv) && mesh_clip(m, ry.o, inv, t0, t1) && t0 <= bound);
     }
-    if (found) {
-        c.t = leaf_t_to_world(F, o, ry, best);
-        c.ok = true;
-    }
-    return c;
-}
-
-// does the ray pass the Mesh::new box of any mesh of this object?
-RT_DEV bool mesh_object_box_hit(const DevScene &sc, const DevObject &ob, d3 o, d3 d)
-{
-    const DevLeaf &F = sc.leaves[ob.frame];
-    LeafRay ry = to_leaf(F, o, d);
-    d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
-    bool any = false;
-    for (int mi = 0; mi < ob.n_meshes; ++mi) any = any || mesh_box_hit(sc.meshes[ob.mesh0 + mi], ry.o, inv);
     return any;
 }
 
@@ -354,7 +321,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q,
                 case DO_CSG:
                     if (CSG) c = eval_csg_object(sc, ob, o, d, gd);
                     break;
-                case DO_MESH: wants_mesh = wants_mesh || mesh_object_box_hit(sc, ob, o, d); break;
+                case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
                 default:
                     if (MEDIUM) c = eval_medium_object<CSG, TORUS>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
                     break;
@@ -364,6 +331,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q,
                     best_t = c.t;
                     best_obj = k;
                     best_aux = c.aux;
+                }
+            }
+
+            if (wants_mesh) {
+                wants_mesh = false;
+                for (int k = 0; k < sc.n_objects; ++k) {
+                    const DevObject &ob = sc.objects[k];
+                    if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, d, best_obj >= 0, best_t);
                 }
             }
 
@@ -432,38 +407,310 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
     if (primary_ids) primary_ids[q.slot[i]] = best_obj;
 }
 
-// Pass 2: the rays queued by k_intersect against the mesh objects.  A mesh hit
-// replaces the recorded hit when it is nearer, or equally near and earlier in
-// the object list - the order Ray::trace's min_by would have seen.
-__global__ void __launch_bounds__(RT_KD_LANES) k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
-                                                    const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids)
+// Pass 2: the rays queued by k_intersect against the mesh objects
+// (Composite::intersect over Mesh children, composite.rs:20-34, mesh.rs:116-128).
+// A mesh hit replaces the recorded hit when it is nearer, or equally near and
+// earlier in the object list - the order Ray::trace's min_by would have seen.
+//
+// Each lane walks its ray through the mesh's uniform grid.  The grid's occupancy
+// words, distance nibbles and (when they fit) cell starts sit in LDS: a cell at
+// Chebyshev distance k from the nearest occupied cell lets the ray jump k-1 cells
+// ahead, cells next to occupied ones are crossed one boundary at a time (3D-DDA),
+// and only an occupied cell goes to memory, for its run of triangle records.  The
+// walk ends when the nearest hit so far lies before the exit of the current cell:
+// every triangle with a nearer hit touches a cell already visited (cells are padded
+// by far more than the rounding of the walk).
+//
+// The walk is done in grid coordinates (cells are unit cubes, the ray parameter is
+// unchanged): p_g(t) = og + dg * t.
+//
+// Waves take blocks of 64 queue entries, interleaved; with more than one block per
+// wave (large queues) a wave refills its finished lanes once `refill` of them are idle.
+// The walk state is kept in plain scalars (not an aggregate): selecting a field by axis
+// would otherwise be compiled into an indexed access to a copy in scratch memory.
+#define WALK_LOCATE_AXIS(OG, DG, IG, N, C, TM)                                                                         \
+    do {                                                                                                               \
+        double f_ = floor((OG) + (DG) * w_tc);                                                                         \
+        const double top_ = (double)((N) - 1u);                                                                        \
+        f_ = f_ > 0.0 ? f_ : 0.0; /* also sends a NaN to cell 0 */                                                     \
+        f_ = f_ > top_ ? top_ : f_;                                                                                    \
+        (C) = (int)f_;                                                                                                 \
+        const double edge_ = (double)((C) + ((DG) > 0.0 ? 1 : 0));                                                     \
+        (TM) = (DG) != 0.0 ? (edge_ - (OG)) * (IG) : 1.0e300; /* parallel to the planes: never crosses one */          \
+    } while (0)
+// cell and boundary parameters of the point at ray parameter w_tc
+#define WALK_LOCATE()                                                                                                  \
+    do {                                                                                                               \
+        WALK_LOCATE_AXIS(ogx, dgx, igx, nx, cx, tmx);                                                                  \
+        WALK_LOCATE_AXIS(ogy, dgy, igy, ny, cy, tmy);                                                                  \
+        WALK_LOCATE_AXIS(ogz, dgz, igz, nz, cz, tmz);                                                                  \
+    } while (0)
+// cross the nearest cell boundary; OK = false when that leaves the grid or passes t_end
+#define WALK_STEP(OK)                                                                                                  \
+    do {                                                                                                               \
+        const bool ax_ = tmx <= tmy && tmx <= tmz;                                                                     \
+        const bool ay_ = !ax_ && tmy <= tmz;                                                                           \
+        const bool az_ = !ax_ && !ay_;                                                                                 \
+        const double t_exit_ = ax_ ? tmx : (ay_ ? tmy : tmz);                                                          \
+        const double ia_ = ax_ ? igx : (ay_ ? igy : igz);                                                              \
+        const int ca_ = (ax_ ? cx : (ay_ ? cy : cz)) + (ia_ > 0.0 ? 1 : -1);                                           \
+        const uint32_t na_ = ax_ ? nx : (ay_ ? ny : nz);                                                               \
+        (OK) = !(ca_ < 0 || ca_ >= (int)na_ || t_exit_ > t_end);                                                       \
+        if (OK) {                                                                                                      \
+            w_tc = t_exit_;                                                                                            \
+            const double step_ = fabs(ia_);                                                                            \
+            cx = ax_ ? ca_ : cx;                                                                                       \
+            cy = ay_ ? ca_ : cy;                                                                                       \
+            cz = az_ ? ca_ : cz;                                                                                       \
+            tmx = ax_ ? tmx + step_ : tmx;                                                                             \
+            tmy = ay_ ? tmy + step_ : tmy;                                                                             \
+            tmz = az_ ? tmz + step_ : tmz;                                                                             \
+        }                                                                                                              \
+    } while (0)
+
+__global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
+                                                      const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
+                                                      uint32_t refill, uint32_t block_arg, uint32_t resident_waves)
 {
-    __shared__ uint2 kd_stack[DEV_KD_STACK * RT_KD_LANES];
-    uint2 *stk = kd_stack + threadIdx.x;
+    extern __shared__ uint2 grid_lds[]; // (bits, rank) pairs, distance words, then the cell starts if they fit
+    uint32_t *dist_lds = reinterpret_cast<uint32_t *>(grid_lds + sc.n_grid_words);
+    uint32_t *starts_lds = dist_lds + sc.n_dist_words;
+    const bool starts_in_lds = sc.n_cell_starts <= DEV_GRID_MAX_STARTS;
+    {
+        const uint2 *gw = reinterpret_cast<const uint2 *>(sc.grid_bits);
+        for (uint32_t i = threadIdx.x; i < sc.n_grid_words; i += blockDim.x) grid_lds[i] = gw[i];
+        for (uint32_t i = threadIdx.x; i < sc.n_dist_words; i += blockDim.x) dist_lds[i] = sc.grid_dist[i];
+        if (starts_in_lds)
+            for (uint32_t i = threadIdx.x; i < sc.n_cell_starts; i += blockDim.x) starts_lds[i] = sc.cell_start[i];
+    }
+    __syncthreads();
+
+    // every wave takes blocks of 64 queue entries, interleaved with the other waves: neighbouring
+    // rays cost about the same, so contiguous chunks would leave whole waves with the expensive ones
     const uint32_t count = *mesh_count;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
-        const uint32_t i = mesh_queue[j];
-        d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
-        d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
-        int best_obj = hit.obj[i];
-        double best_t = best_obj >= 0 ? hit.t[i] : DBL_MAX;
-        uint32_t best_aux = 0u;
-        bool replaced = false;
-        for (int k = 0; k < sc.n_objects; ++k) {
-            const DevObject &ob = sc.objects[k];
-            if (ob.kind != DO_MESH) continue;
-            Candidate c = eval_mesh_object(sc, ob, o, d, stk);
-            if (c.ok && c.t >= 0.0 && c.t < DBL_MAX &&
-                (best_obj < 0 || c.t < best_t || (c.t == best_t && k < best_obj))) {
-                best_t = c.t;
-                best_obj = k;
-                best_aux = c.aux;
-                replaced = true;
+    const uint32_t n_waves = gridDim.x * (RT_MESH_LANES / 64);
+    const uint32_t wave = blockIdx.x * (RT_MESH_LANES / 64) + (threadIdx.x >> 6);
+    const uint64_t lane_lt = (1ull << lane_id()) - 1ull;
+    // short queues: fewer rays per wave (16 or 32 lanes used), so that the slowest wave of the pass is
+    // done sooner; the queue length is only known here, the host sized the grid from an upper bound
+    uint32_t block = block_arg;
+    if (block == 0u) {
+        const uint32_t spread = n_waves < resident_waves ? n_waves : resident_waves;
+        block = 16u;
+        while (block < 64u && (uint64_t)block * spread < count) block <<= 1;
+    }
+    uint64_t cursor = (uint64_t)wave * block; // next queue entry of this wave
+    uint64_t block_end = cursor + block;      // end of its current block
+
+    // lane state
+    bool active = false, have_ray = false;
+    uint32_t ri = 0;
+    d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1); // ray in the current object's space
+    int k = -1, mi = 0;
+    double best_t = 0.0, wbound = 0.0; // nearest world hit so far; the same as a bound in object space
+    int best_obj = -1;
+    uint32_t best_aux = 0u;
+    bool replaced = false;
+    double obj_t = 0.0;
+    uint32_t obj_aux = 0u;
+    bool obj_found = false;
+    // walk state: grid-space origin, direction, 1 / direction; ray parameter at the next cell
+    // boundary per axis; where the current cell was entered; where the walk ends
+    double ogx = 0, ogy = 0, ogz = 0, dgx = 0, dgy = 0, dgz = 0, igx = 0, igy = 0, igz = 0;
+    double tmx = 0, tmy = 0, tmz = 0, w_tc = 0, t_end = 0;
+    int cx = 0, cy = 0, cz = 0;
+    uint32_t nx = 1, ny = 1, nz = 1, bits0 = 0, cell0 = 0, dist0 = 0;
+    double mt = 1.0e300;
+    uint32_t mtri = 0xFFFFFFFFu;
+
+    for (;;) {
+        // ---------------------------------------------------------------- service finished lanes
+        const bool wants = !active && (have_ray || (cursor < count && lane_id() < block));
+        const uint32_t n_wants = (uint32_t)__popcll(__ballot(wants));
+        const bool none_active = __ballot(active) == 0ull;
+        if (none_active && n_wants == 0u) break;
+        if (n_wants >= refill || none_active) {
+            d3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1);
+            bool advance = false;
+            if (!active && have_ray) {
+                wo = mk3(q.o[0][ri], q.o[1][ri], q.o[2][ri]);
+                wd = mk3(q.d[0][ri], q.d[1][ri], q.d[2][ri]);
+                // result of the walk that just ended: min_by keeps the first minimum
+                if (mtri != 0xFFFFFFFFu && (!obj_found || mt < obj_t)) {
+                    obj_t = mt;
+                    obj_aux = ((uint32_t)mi << 24) | (mtri & 0xFFFFFFu);
+                    obj_found = true;
+                }
+                advance = true;
+            }
+            const bool takes = !active && !have_ray && lane_id() < block;
+            const uint64_t empty = __ballot(takes);
+            if (takes) {
+                const uint64_t j = cursor + (uint64_t)__popcll(empty & lane_lt);
+                if (j < block_end && j < count) {
+                    ri = mesh_queue[j];
+                    wo = mk3(q.o[0][ri], q.o[1][ri], q.o[2][ri]);
+                    wd = mk3(q.d[0][ri], q.d[1][ri], q.d[2][ri]);
+                    best_obj = hit.obj[ri];
+                    best_t = best_obj >= 0 ? hit.t[ri] : DBL_MAX;
+                    best_aux = 0u;
+                    replaced = false;
+                    have_ray = true;
+                    k = -1;
+                    mi = 0;
+                    obj_found = false;
+                    advance = true;
+                }
+            }
+            cursor += (uint64_t)__popcll(empty);
+            if (cursor >= block_end) { // block used up (lanes left without a ray take from the next one)
+                cursor = block_end + (uint64_t)(n_waves - 1u) * block;
+                block_end = cursor + block;
+            }
+            if (advance) {
+                // next (object, mesh) whose boxes the ray passes; closing an object merges its
+                // nearest triangle into the ray's hit
+                bool found = false;
+                for (int guard = 0; guard < 1 << 20; ++guard) {
+                    if (k >= 0) ++mi;
+                    if (k < 0 || mi >= sc.objects[k].n_meshes) {
+                        if (k >= 0 && obj_found) {
+                            const DevLeaf &F = sc.leaves[sc.objects[k].frame];
+                            LeafRay ry;
+                            ry.o = o;
+                            ry.d = d;
+                            double tw = leaf_t_to_world(F, wo, ry, obj_t);
+                            if (tw >= 0.0 && tw < DBL_MAX &&
+                                (best_obj < 0 || tw < best_t || (tw == best_t && k < best_obj))) {
+                                best_t = tw;
+                                best_obj = k;
+                                best_aux = obj_aux;
+                                replaced = true;
+                            }
+                        }
+                        ++k;
+                        while (k < sc.n_objects && sc.objects[k].kind != DO_MESH) ++k;
+                        if (k >= sc.n_objects) break;
+                        const DevLeaf &F = sc.leaves[sc.objects[k].frame];
+                        LeafRay ry = to_leaf(F, wo, wd);
+                        o = ry.o;
+                        d = ry.d;
+                        // a hit farther than the nearest one so far cannot win: object-space distance
+                        // = world distance * |W d|; the slack keeps exact ties in play
+                        const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, wd));
+                        wbound = best_obj >= 0 ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
+                        obj_found = false;
+                        mi = 0;
+                    }
+                    const DevMesh &m = sc.meshes[sc.objects[k].mesh0 + mi];
+                    const d3 inv = mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                    if (!mesh_box_hit(m, o, inv)) continue;
+                    double t0, t1;
+                    if (!mesh_clip(m, o, inv, t0, t1)) continue;
+                    if (wbound < t1) t1 = wbound;
+                    if (obj_found && obj_t < t1) t1 = obj_t; // a later mesh must be strictly nearer
+                    if (t0 > t1) continue;
+                    // enter the grid at t0
+                    ogx = (o.x - m.bmin[0]) * m.inv_cell[0];
+                    ogy = (o.y - m.bmin[1]) * m.inv_cell[1];
+                    ogz = (o.z - m.bmin[2]) * m.inv_cell[2];
+                    dgx = d.x * m.inv_cell[0];
+                    dgy = d.y * m.inv_cell[1];
+                    dgz = d.z * m.inv_cell[2];
+                    igx = 1.0 / dgx;
+                    igy = 1.0 / dgy;
+                    igz = 1.0 / dgz;
+                    nx = m.n[0];
+                    ny = m.n[1];
+                    nz = m.n[2];
+                    w_tc = t0;
+                    t_end = t1;
+                    bits0 = m.bits0;
+                    cell0 = m.cell0;
+                    dist0 = m.dist0;
+                    WALK_LOCATE();
+                    mt = 1.0e300;
+                    mtri = 0xFFFFFFFFu;
+                    found = true;
+                    break;
+                }
+                if (found) {
+                    active = true;
+                } else {
+                    if (replaced) write_mesh_hit(sc, q, hit, primary_ids, ri, wo, wd, best_t, best_obj, best_aux);
+                    have_ray = false;
+                }
+            }
+            continue; // re-evaluate: lanes whose new ray needed no walk can be filled again
+        }
+
+        // ---------------------------------------------------------------- walk to the next occupied cell
+        // "while-while": all lanes first move to their next occupied cell (LDS only), then the wave
+        // tests triangles together (the expensive part).
+        if (active) {
+            uint32_t cell = 0u;
+            bool occupied = false;
+            for (int step = 0; step < 3 * DEV_GRID_MAX_AXIS + 3; ++step) {
+                cell = ((uint32_t)cz * ny + (uint32_t)cy) * nx + (uint32_t)cx;
+                const uint32_t kd = (dist_lds[dist0 + (cell >> 3)] >> ((cell & 7u) * 4u)) & 15u;
+                if (kd == 0u) {
+                    occupied = true;
+                    break;
+                }
+                if (kd >= 2u) {
+                    // nothing within kd-1 cells of this one along any axis
+                    const double dmin = fmin(fmin(fabs(igx), fabs(igy)), fabs(igz));
+                    w_tc += ((double)kd - 1.01) * dmin;
+                    if (w_tc > t_end) {
+                        active = false;
+                        break;
+                    }
+                    WALK_LOCATE();
+                } else {
+                    bool ok;
+                    WALK_STEP(ok);
+                    if (!ok) {
+                        active = false;
+                        break;
+                    }
+                }
+            }
+            if (active && occupied) {
+                const uint2 gw = grid_lds[bits0 + (cell >> 5)];
+                const uint32_t r = cell0 + gw.y + (uint32_t)__popc(gw.x & ((1u << (cell & 31u)) - 1u));
+                uint32_t first, last;
+                if (starts_in_lds) {
+                    first = starts_lds[r];
+                    last = starts_lds[r + 1u];
+                } else {
+                    first = sc.cell_start[r];
+                    last = sc.cell_start[r + 1u];
+                }
+                // one record ahead: the loads of the next triangle are in flight during the test of this one
+                const double2 *__restrict__ rec = reinterpret_cast<const double2 *>(sc.cell_tris + (size_t)first * 10);
+                double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+                for (uint32_t e = first; e < last; ++e) {
+                    const d3 v0 = mk3(r0.x, r0.y, r1.x), e1 = mk3(r1.y, r2.x, r2.y), e2 = mk3(r3.x, r3.y, r4.x);
+                    const uint32_t ti = (uint32_t)__double2loint(r4.y);
+                    if (e + 1u < last) {
+                        rec += 5;
+                        r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+                    }
+                    double t, u, v;
+                    if (tri_hit_v(v0, e1, e2, o, d, t, u, v)) {
+                        if (t < mt || (t == mt && ti < mtri)) {
+                            mt = t;
+                            mtri = ti;
+                        }
+                    }
+                }
+                // leave the cell, unless the hit found lies before its far side (slack: rounding)
+                const double t_exit = fmin(fmin(tmx, tmy), tmz);
+                bool ok = !(mt < t_exit - 1e-9 * (fabs(t_exit) + 1.0));
+                if (ok) WALK_STEP(ok);
+                if (!ok) active = false;
             }
         }
-        if (!replaced) continue;
-        write_mesh_hit(sc, q, hit, primary_ids, i, o, d, best_t, best_obj, best_aux);
     }
 }
 
@@ -800,6 +1047,7 @@ struct rt_scene {
     HitBuf hit;
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
     uint64_t n_mesh_tris = 0;
+    uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
     uint32_t *mesh_queue = nullptr; // ray indices that need the kd-trees this pass
     uint32_t *d_counts = nullptr; // 2 x (max_depth + 2): live rays per depth, then mesh-queue lengths per depth
     uint32_t counts_cap = 0;
@@ -894,7 +1142,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
         rt_host::set_last_error("rt_scene_create: " + err);
         return rc;
     }
-    RT_TRACE("flattened: %zu objects %zu leaves %zu kd nodes", flat.objects.size(), flat.leaves.size(), flat.kd.size());
+    RT_TRACE("flattened: %zu objects %zu leaves %zu grid words %zu cell refs", flat.objects.size(), flat.leaves.size(),
+             flat.grid_bits.size(), flat.cell_tris.size() / 10);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         rt_host::set_last_error("rt_scene_create: no HIP device available (this library has no CPU path)");
@@ -911,10 +1160,16 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     if ((rc = upload(s, flat.leaves, &s->dev.leaves))) return fail(rc);
     if ((rc = upload(s, flat.prog, &s->dev.prog))) return fail(rc);
     if ((rc = upload(s, flat.meshes, &s->dev.meshes))) return fail(rc);
-    if ((rc = upload(s, flat.kd, &s->dev.kd))) return fail(rc);
-    if ((rc = upload(s, flat.kd_index, &s->dev.kd_index))) return fail(rc);
+    if ((rc = upload(s, flat.grid_bits, &s->dev.grid_bits))) return fail(rc);
+    if ((rc = upload(s, flat.cell_start, &s->dev.cell_start))) return fail(rc);
+    s->dev.n_grid_words = (uint32_t)(flat.grid_bits.size() / 2);
+    if ((rc = upload(s, flat.grid_dist, &s->dev.grid_dist))) return fail(rc);
+    s->dev.n_cell_starts = (uint32_t)flat.cell_start.size();
+    s->dev.n_dist_words = (uint32_t)flat.grid_dist.size();
+    s->mesh_lds_bytes = s->dev.n_grid_words * 8u + s->dev.n_dist_words * 4u +
+                        (s->dev.n_cell_starts <= DEV_GRID_MAX_STARTS ? s->dev.n_cell_starts * 4u : 0u);
     if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
-    if ((rc = upload(s, flat.leaf_tris, &s->dev.leaf_tris))) return fail(rc);
+    if ((rc = upload(s, flat.cell_tris, &s->dev.cell_tris))) return fail(rc);
     if ((rc = upload(s, flat.tri_n, &s->dev.tri_n))) return fail(rc);
     if ((rc = upload(s, flat.normals, &s->dev.normals))) return fail(rc);
     if ((rc = upload(s, flat.materials, &s->dev.materials))) return fail(rc);
@@ -1016,10 +1271,17 @@ static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const R
             hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), block, 0, st, s->dev, q, s->mesh_queue, mesh_count,
                                s->hit, ids);
         } else {
-            uint64_t mb = ((uint64_t)live + RT_KD_LANES - 1) / RT_KD_LANES;
-            if (mb > 256 * 16) mb = 256 * 16;
-            hipLaunchKernelGGL(k_mesh, dim3((uint32_t)mb), dim3(RT_KD_LANES), 0, st, s->dev, q, s->mesh_queue, mesh_count,
-                               s->hit, ids);
+            // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
+            // waves stay and refill their idle lanes from further blocks
+            static const uint32_t refill = getenv("RT_MESH_REFILL") ? (uint32_t)atoi(getenv("RT_MESH_REFILL")) : 16u;
+            static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * 6u;
+            static const uint32_t block_env = getenv("RT_MESH_BLOCK") ? (uint32_t)atoi(getenv("RT_MESH_BLOCK")) : 0u;
+            const uint64_t per_wg = 16u * (RT_MESH_LANES / 64); // the kernel uses 16, 32 or 64 lanes per wave
+            uint64_t mb = ((uint64_t)live + per_wg - 1) / per_wg;
+            if (mb < 1) mb = 1;
+            if (mb > max_wgs) mb = max_wgs;
+            hipLaunchKernelGGL(k_mesh, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_lds_bytes, st, s->dev, q,
+                               s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES);
         }
     }
 }
@@ -1118,6 +1380,11 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (opts->max_depth + 1) * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
+                if (rt_debug()) {
+                    std::vector<uint32_t> mc(opts->max_depth + 1);
+                    (void)hipMemcpy(mc.data(), s->d_counts + (opts->max_depth + 2), mc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                    for (uint32_t k = 0; k < passes; ++k) RT_TRACE("pass %u: rays %u mesh queue %u", k, s->h_pinned[k], mc[k]);
+                }
                 local.primary_rays += s->h_pinned[0];
                 for (uint32_t k = 0; k < opts->max_depth; ++k) local.rays += s->h_pinned[k];
                 {
@@ -1148,21 +1415,6 @@ finished:
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
     local.interval_overflow = s->h_pinned[5];
-#ifdef RT_KD_STATS
-    {
-        unsigned long long it = 0, tr = 0, ry = 0;
-        unsigned int mx = 0;
-        (void)hipMemcpyFromSymbol(&it, HIP_SYMBOL(g_kd_iters), 8);
-        (void)hipMemcpyFromSymbol(&tr, HIP_SYMBOL(g_kd_tris), 8);
-        (void)hipMemcpyFromSymbol(&ry, HIP_SYMBOL(g_kd_rays), 8);
-        (void)hipMemcpyFromSymbol(&mx, HIP_SYMBOL(g_kd_max), 4);
-        unsigned long long cy = 0, mc = 0;
-        (void)hipMemcpyFromSymbol(&cy, HIP_SYMBOL(g_kd_cyc), 8);
-        (void)hipMemcpyFromSymbol(&mc, HIP_SYMBOL(g_kd_maxcyc), 8);
-        fprintf(stderr, "[kd] traversals %llu  steps/ray %.1f  tris/ray %.1f  max steps %u  cycles/ray %.0f  max cycles %llu\n", ry,
-                ry ? (double)it / ry : 0.0, ry ? (double)tr / ry : 0.0, mx, ry ? (double)cy / ry : 0.0, mc);
-    }
-#endif
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     local.ms_device = ms;
