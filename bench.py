@@ -12,8 +12,9 @@ final image.  The frame's seed changes every step, so nothing can be cached.
 value = rays traced by all ranks in the K timed steps / max-over-ranks time.
 
 Extra objects on the JSON line (see DESIGN.md "Measurement"):
-  roofline      dominant kernel k_intersect: algorithmic bytes (132 B per ray:
-                80-B ray record in, 52-B hit record out) / its HIP-event time
+  roofline      the dominant kernel by GPU time (k_mesh, the grid walk of the rays queued for
+                the mesh): algorithmic bytes per queued ray / its HIP-event time; the other
+                kernels of the frame are listed under "kernels" the same way
   frame_hbm     SURVEY 8(d)'s whole-frame figure: (264 B/ray + 24 B/pixel-sample) / frame time
   cpu_baseline  the CPU oracle (a restatement of the reference, `kind: port`) on a
                 bounded sample of the same scene; N=1, rank 0 only
@@ -30,7 +31,9 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SAMPLES = 3840, 2160, 1
 SCENE = "mesh"
-BYTES_PER_RAY_INTERSECT = 80 + 52   # ray record read + hit record written
+BYTES_PER_RAY_INTERSECT = 52 + 52   # origin, direction, pixel read + hit record written
+BYTES_PER_RAY_MESH = 4 + 48 + 12 + 52  # queue entry, origin + direction, recorded hit (t, object) read; hit record written
+BYTES_PER_RAY_SHADE = 80 + 52 + 80  # ray + hit read, scattered ray written (or 24 B of frame buffer updated)
 BYTES_PER_RAY_FRAME = 2 * 80 + 2 * 52
 BYTES_PER_PIXEL_SAMPLE = 24
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -130,17 +133,20 @@ def main():
     barrier()
     t0 = time.perf_counter()
     rays = 0
-    ms_int = 0.0
-    n_int = 0
-    ms_shade = 0.0
-    int_rays = 0
+    acc = dict(ms_int=0.0, ms_mesh=0.0, ms_shade=0.0, ms_tail=0.0, ms_raygen=0.0, n_int=0, n_mesh=0, int_rays=0,
+               mesh_rays=0)
     for k in range(args.steps):
         st = step(args.warmup + k)
         rays += st.rays
-        ms_int += st.ms_intersect
-        ms_shade += st.ms_shade
-        n_int += st.n_intersect_launches
-        int_rays += st.rays
+        acc["ms_int"] += st.ms_intersect
+        acc["ms_mesh"] += st.ms_mesh
+        acc["ms_shade"] += st.ms_shade
+        acc["ms_tail"] += st.ms_tail
+        acc["ms_raygen"] += st.ms_raygen
+        acc["n_int"] += st.n_intersect_launches
+        acc["n_mesh"] += st.n_mesh_launches
+        acc["int_rays"] += st.intersect_rays
+        acc["mesh_rays"] += st.mesh_rays
     barrier()
     dt = time.perf_counter() - t0
 
@@ -158,16 +164,27 @@ def main():
     if rank == 0:
         value = rays_total / dt / 1e6
         ms_step = dt / args.steps * 1e3
-        # dominant kernel: k_intersect on this rank
-        ach = (int_rays * BYTES_PER_RAY_INTERSECT) / (ms_int * 1e-3) / 1e9 if ms_int > 0 else 0.0
+        def line(kernel, rays_k, bytes_per_ray, ms, launches):
+            ach = rays_k * bytes_per_ray / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch":
+                    rays_k / launches if launches else None, "avg_launch_ms": ms / launches if launches else None,
+                    "launches": launches, "ms_per_step": ms / args.steps}
+        kernels = [line("k_mesh", acc["mesh_rays"], BYTES_PER_RAY_MESH, acc["ms_mesh"], acc["n_mesh"]),
+                   line("k_intersect", acc["int_rays"], BYTES_PER_RAY_INTERSECT, acc["ms_int"], acc["n_int"]),
+                   line("k_shade", acc["int_rays"], BYTES_PER_RAY_SHADE, acc["ms_shade"], acc["n_int"])]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("k_intersect_hbm_bytes_per_launch")
+                    traffic = json.load(f).get("k_mesh_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        roof = dict(kernels[0])
+        roof["traffic"] = traffic
+        roof["note"] = ("ms_mesh is the k_mesh + k_mesh_brute stage; k_mesh is a latency-bound grid walk, its HBM "
+                        "fraction is low by construction (DESIGN.md)")
         frame_bytes = rays_total * BYTES_PER_RAY_FRAME + args.width * args.height * args.samples * BYTES_PER_PIXEL_SAMPLE * args.steps
         out = {
             "metric": "Mrays/sec (primary+secondary) at 4K, mesh.scene",
@@ -177,11 +194,11 @@ def main():
             "config": {"workload": "%s.scene %dx%d samples=%d max_depth=50, seed=1+step" %
                                    (args.scene, args.width, args.height, args.samples),
                        "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps},
-            "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_ray": BYTES_PER_RAY_INTERSECT,
-                         "avg_launch_ms": ms_int / n_int if n_int else None, "launches": n_int,
-                         "ms_intersect_per_step": ms_int / args.steps, "ms_shade_per_step": ms_shade / args.steps},
+            "roofline": roof,
+            "kernels": kernels[1:],
+            "stage_ms_per_step": {"raygen": acc["ms_raygen"] / args.steps, "intersect": acc["ms_int"] / args.steps,
+                                  "mesh": acc["ms_mesh"] / args.steps, "shade": acc["ms_shade"] / args.steps,
+                                  "tail": acc["ms_tail"] / args.steps},
             "frame_hbm": {"bytes_per_ray": BYTES_PER_RAY_FRAME, "bytes_per_pixel_sample": BYTES_PER_PIXEL_SAMPLE,
                           "achieved": frame_bytes / dt / 1e9 / world, "unit": "GB/s per GPU",
                           "frac": frame_bytes / dt / 1e9 / world / HBM_PEAK_GBS},

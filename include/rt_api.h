@@ -177,7 +177,7 @@ typedef struct rt_stats {
     uint64_t rays;         /* Ray::trace invocations, primary + secondary  */
     uint64_t primary_rays; /* of which depth 0                             */
     uint32_t strata;       /* strata rendered = floor(sqrt(samples))^2     */
-    uint32_t bounce_passes; /* intersect launches issued                   */
+    uint32_t bounce_passes; /* path depths that had rays                    */
     /* Situations in which the reference panics; the device
      * treats them as a miss and counts them: cube >2 face hits, torus
      * three-root mismatch, CSG "unanticipated difference case", cylinder
@@ -187,10 +187,14 @@ typedef struct rt_stats {
     double ms_device;           /* GPU time of the call, HIP events on its stream */
     /* per-kernel GPU time, HIP events on the same stream, summed over launches */
     double ms_raygen;
-    double ms_intersect;
+    double ms_intersect; /* k_intersect: every object except the triangles      */
     double ms_shade;
-    uint32_t n_intersect_launches;
-    uint32_t pad;
+    double ms_mesh;      /* k_mesh / k_mesh_brute: the rays queued for a mesh   */
+    double ms_tail;      /* k_tail: the last few paths, all remaining bounces   */
+    uint32_t n_intersect_launches; /* k_intersect launches that had rays        */
+    uint32_t n_mesh_launches;      /* k_mesh (grid walk) launches               */
+    uint64_t mesh_rays;            /* rays those k_mesh launches walked         */
+    uint64_t intersect_rays;       /* rays those k_intersect launches took      */
 } rt_stats;
 
 /* Nearest-hit record, one per ray: RayHit (system.rs:154-171). */

@@ -81,7 +81,9 @@ class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("strata", C.c_uint32),
                 ("bounce_passes", C.c_uint32), ("guards", C.c_uint32 * 5), ("interval_overflow", C.c_uint32),
                 ("ms_device", C.c_double), ("ms_raygen", C.c_double), ("ms_intersect", C.c_double),
-                ("ms_shade", C.c_double), ("n_intersect_launches", C.c_uint32), ("pad", C.c_uint32)]
+                ("ms_shade", C.c_double), ("ms_mesh", C.c_double), ("ms_tail", C.c_double),
+                ("n_intersect_launches", C.c_uint32), ("n_mesh_launches", C.c_uint32),
+                ("mesh_rays", C.c_uint64), ("intersect_rays", C.c_uint64)]
 
 
 class rt_hit(C.Structure):

@@ -287,6 +287,82 @@ __device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const D
 // `mesh_queue`; k_mesh then walks the kd-trees with full waves and merges its
 // result into the hit record.  CSG / MEDIUM prune code (and registers) the
 // scene does not need.
+struct HitRec {
+    double t; // -1: nothing hit
+    d3 n;
+    double u, v;
+    int obj;
+};
+
+// Ray::trace (system.rs:122-133) over every object except the triangle work; returns whether
+// the ray still has to visit a mesh.
+template <bool CSG, bool MEDIUM, bool TORUS>
+RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, const PassParams &pp, HitRec &h, Guards &gd)
+{
+    bool wants_mesh = false;
+    // first object wins ties, t must be < f64::MAX
+    double best_t = DBL_MAX;
+    int best_obj = -1;
+    uint32_t best_aux = 0u;
+    for (int k = 0; k < sc.n_objects; ++k) {
+        const DevObject &ob = sc.objects[k];
+        Candidate c;
+        c.ok = false;
+        c.t = 0.0;
+        c.aux = 0u;
+        switch (ob.kind) {
+        case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
+        case DO_CSG:
+            if (CSG) c = eval_csg_object(sc, ob, o, d, gd);
+            break;
+        case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
+        default:
+            if (MEDIUM) c = eval_medium_object<CSG, TORUS>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
+            break;
+        }
+        // Object::intersect keeps t >= 0 (object.rs:50-54)
+        if (c.ok && c.t >= 0.0 && c.t < DBL_MAX && (best_obj < 0 || c.t < best_t)) {
+            best_t = c.t;
+            best_obj = k;
+            best_aux = c.aux;
+        }
+    }
+
+    if (wants_mesh) {
+        wants_mesh = false;
+        for (int k = 0; k < sc.n_objects; ++k) {
+            const DevObject &ob = sc.objects[k];
+            if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, d, best_obj >= 0, best_t);
+        }
+    }
+
+    d3 n = mk3(0.0, 0.0, 0.0);
+    double u = 0.0, v = 0.0;
+    if (best_obj >= 0) {
+        const DevObject &ob = sc.objects[best_obj];
+        const bool need_uv = ob.needs_uv || pp.force_uv;
+        d3 pw = o + d * best_t;
+        if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
+            const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
+            LeafRay ry = to_leaf(L, o, d);
+            d3 ql = L.identity ? pw : xf_point(L.W, pw);
+            d3 nl;
+            leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
+            n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
+            if (best_aux & TAG_NEG) n = -n;
+        } else {
+            const DevLeaf &F = sc.leaves[ob.frame];
+            n = F.identity ? mk3(1.0, 0.0, 0.0) : normalize3(xf_normal(F.W, mk3(1.0, 0.0, 0.0)));
+        }
+    }
+    h.t = best_obj >= 0 ? best_t : -1.0;
+    h.n = n;
+    h.u = u;
+    h.v = v;
+    h.obj = best_obj;
+    return wants_mesh;
+}
+
 template <bool CSG, bool MEDIUM, bool TORUS>
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
@@ -305,70 +381,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q,
             d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
             d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
             uint32_t pixel = q.pixel[i];
-
-            // Ray::trace (system.rs:122-133): first object wins ties, t must be < f64::MAX
-            double best_t = DBL_MAX;
-            int best_obj = -1;
-            uint32_t best_aux = 0u;
-            for (int k = 0; k < sc.n_objects; ++k) {
-                const DevObject &ob = sc.objects[k];
-                Candidate c;
-                c.ok = false;
-                c.t = 0.0;
-                c.aux = 0u;
-                switch (ob.kind) {
-                case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
-                case DO_CSG:
-                    if (CSG) c = eval_csg_object(sc, ob, o, d, gd);
-                    break;
-                case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
-                default:
-                    if (MEDIUM) c = eval_medium_object<CSG, TORUS>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
-                    break;
-                }
-                // Object::intersect keeps t >= 0 (object.rs:50-54)
-                if (c.ok && c.t >= 0.0 && c.t < DBL_MAX && (best_obj < 0 || c.t < best_t)) {
-                    best_t = c.t;
-                    best_obj = k;
-                    best_aux = c.aux;
-                }
-            }
-
-            if (wants_mesh) {
-                wants_mesh = false;
-                for (int k = 0; k < sc.n_objects; ++k) {
-                    const DevObject &ob = sc.objects[k];
-                    if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, d, best_obj >= 0, best_t);
-                }
-            }
-
-            d3 n = mk3(0.0, 0.0, 0.0);
-            double u = 0.0, v = 0.0;
-            if (best_obj >= 0) {
-                const DevObject &ob = sc.objects[best_obj];
-                const bool need_uv = ob.needs_uv || pp.force_uv;
-                d3 pw = o + d * best_t;
-                if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
-                    const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
-                    LeafRay ry = to_leaf(L, o, d);
-                    d3 ql = L.identity ? pw : xf_point(L.W, pw);
-                    d3 nl;
-                    leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
-                    n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
-                    if (best_aux & TAG_NEG) n = -n;
-                } else {
-                    const DevLeaf &F = sc.leaves[ob.frame];
-                    n = F.identity ? mk3(1.0, 0.0, 0.0) : normalize3(xf_normal(F.W, mk3(1.0, 0.0, 0.0)));
-                }
-            }
-            hit.t[i] = best_obj >= 0 ? best_t : -1.0;
-            hit.n[0][i] = n.x;
-            hit.n[1][i] = n.y;
-            hit.n[2][i] = n.z;
-            hit.uv[0][i] = u;
-            hit.uv[1][i] = v;
-            hit.obj[i] = best_obj;
-            if (primary_ids) primary_ids[q.slot[i]] = best_obj;
+            HitRec h;
+            wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
+            hit.t[i] = h.t;
+            hit.n[0][i] = h.n.x;
+            hit.n[1][i] = h.n.y;
+            hit.n[2][i] = h.n.z;
+            hit.uv[0][i] = h.u;
+            hit.uv[1][i] = h.v;
+            hit.obj[i] = h.obj;
+            if (primary_ids) primary_ids[q.slot[i]] = h.obj;
         }
         uint32_t at = block_append(wants_mesh, mesh_count, append_lds);
         if (wants_mesh) mesh_queue[at] = i;
@@ -378,16 +400,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DevScene sc, RayQueue q,
     if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
 }
 
-// normal / uv of a mesh hit (mesh.rs:97-112 + the Composite's to_world) into the hit record
-RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &hit, int32_t *primary_ids, uint32_t i,
-                           d3 o, d3 d, double best_t, int best_obj, uint32_t best_aux)
+// normal / uv of a mesh hit (mesh.rs:97-112 + the Composite's to_world)
+RT_DEV void mesh_hit_surface(const DevScene &sc, d3 o, d3 d, int best_obj, uint32_t best_aux, d3 &n, double &u, double &v)
 {
     const DevObject &ob = sc.objects[best_obj];
     const DevLeaf &F = sc.leaves[ob.frame];
     const DevMesh &m = sc.meshes[ob.mesh0 + (best_aux >> 24)];
     LeafRay ry = to_leaf(F, o, d);
     uint32_t tri = best_aux & 0xFFFFFFu;
-    double tt = 0.0, u = 0.0, v = 0.0;
+    double tt = 0.0;
+    u = 0.0;
+    v = 0.0;
     tri_hit(sc.tris + ((size_t)m.tri0 + tri) * 9, ry.o, ry.d, tt, u, v);
     const uint32_t *tn = sc.tri_n + ((size_t)m.tri0 + tri) * 3;
     const double *nb = sc.normals + (size_t)m.normal0 * 3;
@@ -396,7 +419,15 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
     d3 n2 = mk3(nb[3 * tn[2]], nb[3 * tn[2] + 1], nb[3 * tn[2] + 2]);
     // mesh.rs:102-106
     d3 nl = m.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
-    d3 n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
+    n = F.identity ? nl : normalize3(xf_normal(F.W, nl));
+}
+
+RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &hit, int32_t *primary_ids, uint32_t i,
+                           d3 o, d3 d, double best_t, int best_obj, uint32_t best_aux)
+{
+    d3 n;
+    double u, v;
+    mesh_hit_surface(sc, o, d, best_obj, best_aux, n, u, v);
     hit.t[i] = best_t;
     hit.n[0][i] = n.x;
     hit.n[1][i] = n.y;
@@ -732,13 +763,77 @@ RT_DEV void wave_min_hit(double &t, uint32_t &tri)
     }
 }
 
+// All 64 lanes of the wave hold the same ray.  Returns whether a mesh replaces the hit so far.
+RT_DEV bool mesh_brute_wave(const DevScene &sc, d3 o, d3 d, int &best_obj, double &best_t, uint32_t &best_aux)
+{
+    const uint32_t lane = lane_id();
+    bool replaced = false;
+    for (int k = 0; k < sc.n_objects; ++k) {
+        const DevObject &ob = sc.objects[k];
+        if (ob.kind != DO_MESH) continue;
+        const DevLeaf &F = sc.leaves[ob.frame];
+        LeafRay ry = to_leaf(F, o, d);
+        d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
+        double obj_t = 0.0;
+        uint32_t obj_aux = 0u;
+        bool obj_found = false;
+        for (int mi = 0; mi < ob.n_meshes; ++mi) {
+            const DevMesh &m = sc.meshes[ob.mesh0 + mi];
+            if (!mesh_box_hit(m, ry.o, inv)) continue;
+            const double *__restrict__ tris = sc.tris + (size_t)m.tri0 * 9;
+            double lt = 1.0e300;
+            uint32_t ltri = 0xFFFFFFFFu;
+            // three records per step, loaded before the first test: the loop is bound by the
+            // latency of its loads, and this way three are in flight at a time
+            for (uint32_t base = lane; base < m.n_tris; base += 192u) {
+                const uint32_t i0 = base, i1 = base + 64u, i2 = base + 128u;
+                const uint32_t j1 = i1 < m.n_tris ? i1 : i0, j2 = i2 < m.n_tris ? i2 : i0; // out of range: repeat i0
+                const double *a = tris + (size_t)i0 * 9, *b = tris + (size_t)j1 * 9, *c = tris + (size_t)j2 * 9;
+                const d3 a0 = mk3(a[0], a[1], a[2]), a1 = mk3(a[3], a[4], a[5]), a2 = mk3(a[6], a[7], a[8]);
+                const d3 b0 = mk3(b[0], b[1], b[2]), b1 = mk3(b[3], b[4], b[5]), b2 = mk3(b[6], b[7], b[8]);
+                const d3 c0 = mk3(c[0], c[1], c[2]), c1 = mk3(c[3], c[4], c[5]), c2 = mk3(c[6], c[7], c[8]);
+                double t, u, v;
+                // indices grow within a lane, and a repeated i0 cannot beat itself (t < lt is strict):
+                // the first of equal t's is the lowest index
+                if (tri_hit_v(a0, a1, a2, ry.o, ry.d, t, u, v) && t < lt) {
+                    lt = t;
+                    ltri = i0;
+                }
+                if (tri_hit_v(b0, b1, b2, ry.o, ry.d, t, u, v) && t < lt) {
+                    lt = t;
+                    ltri = j1;
+                }
+                if (tri_hit_v(c0, c1, c2, ry.o, ry.d, t, u, v) && t < lt) {
+                    lt = t;
+                    ltri = j2;
+                }
+            }
+            wave_min_hit(lt, ltri);
+            if (ltri != 0xFFFFFFFFu && (!obj_found || lt < obj_t)) { // min_by keeps the first minimum
+                obj_t = lt;
+                obj_aux = ((uint32_t)mi << 24) | (ltri & 0xFFFFFFu);
+                obj_found = true;
+            }
+        }
+        if (obj_found) {
+            double tw = leaf_t_to_world(F, o, ry, obj_t);
+            if (tw >= 0.0 && tw < DBL_MAX && (best_obj < 0 || tw < best_t || (tw == best_t && k < best_obj))) {
+                best_t = tw;
+                best_obj = k;
+                best_aux = obj_aux;
+                replaced = true;
+            }
+        }
+    }
+    return replaced;
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
                                                           const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids)
 {
     const uint32_t count = *mesh_count;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t lane = lane_id();
     for (uint32_t j = wave; j < count; j += n_waves) {
         const uint32_t i = mesh_queue[j];
         d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
@@ -746,47 +841,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q
         int best_obj = hit.obj[i];
         double best_t = best_obj >= 0 ? hit.t[i] : DBL_MAX;
         uint32_t best_aux = 0u;
-        bool replaced = false;
-        for (int k = 0; k < sc.n_objects; ++k) {
-            const DevObject &ob = sc.objects[k];
-            if (ob.kind != DO_MESH) continue;
-            const DevLeaf &F = sc.leaves[ob.frame];
-            LeafRay ry = to_leaf(F, o, d);
-            d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
-            double obj_t = 0.0;
-            uint32_t obj_aux = 0u;
-            bool obj_found = false;
-            for (int mi = 0; mi < ob.n_meshes; ++mi) {
-                const DevMesh &m = sc.meshes[ob.mesh0 + mi];
-                if (!mesh_box_hit(m, ry.o, inv)) continue;
-                const double *__restrict__ tris = sc.tris + (size_t)m.tri0 * 9;
-                double lt = 1.0e300;
-                uint32_t ltri = 0xFFFFFFFFu;
-                for (uint32_t ti = lane; ti < m.n_tris; ti += 64u) {
-                    double t, u, v;
-                    if (tri_hit(tris + (size_t)ti * 9, ry.o, ry.d, t, u, v) && t < lt) {
-                        lt = t; // ti grows within a lane: the first of equal t's is the lowest index
-                        ltri = ti;
-                    }
-                }
-                wave_min_hit(lt, ltri);
-                if (ltri != 0xFFFFFFFFu && (!obj_found || lt < obj_t)) { // min_by keeps the first minimum
-                    obj_t = lt;
-                    obj_aux = ((uint32_t)mi << 24) | (ltri & 0xFFFFFFu);
-                    obj_found = true;
-                }
-            }
-            if (obj_found) {
-                double tw = leaf_t_to_world(F, o, ry, obj_t);
-                if (tw >= 0.0 && tw < DBL_MAX && (best_obj < 0 || tw < best_t || (tw == best_t && k < best_obj))) {
-                    best_t = tw;
-                    best_obj = k;
-                    best_aux = obj_aux;
-                    replaced = true;
-                }
-            }
-        }
-        if (!replaced || lane != 0) continue;
+        if (!mesh_brute_wave(sc, o, d, best_obj, best_t, best_aux) || lane_id() != 0u) continue;
         write_mesh_hit(sc, q, hit, primary_ids, i, o, d, best_t, best_obj, best_aux);
     }
 }
@@ -872,6 +927,73 @@ RT_DEV d3 refract(d3 inc, d3 nrm, double ior)
 
 RT_DEV d3 reflect3(d3 d, d3 n) { return d - (n * 2.0) * dot3(d, n); } // direction.rs:75-77
 
+// One path segment's end (system.rs:112-120,135-142): either the path goes on (returns true; `o`,
+// `d`, `thr` become the scattered ray and the updated attenuation) or it ends seeing `X`.
+RT_DEV bool shade_one(const DevScene &sc, d3 &o, d3 &d, d3 &thr, uint32_t pixel, const HitRec &h, const PassParams &pp,
+                      d3 bg, d3 &X)
+{
+    X = bg; // what the path sees where it ends
+    if (h.obj < 0) return false;
+    const d3 n = h.n;
+    const double u = h.u, v = h.v;
+    const DevMaterial &m = sc.materials[sc.objects[h.obj].material];
+    d3 p = o + d * h.t; // RayHit::point (system.rs:173-175)
+    d3 att = mk3(1.0, 1.0, 1.0);
+    d3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
+    switch (m.kind) {
+    case RT_MAT_LAMBERTIAN: {
+        // lambertian.rs:20-31
+        no = p + n * pp.bias;
+        d3 target = p + n + uniform_sphere(pp, pixel);
+        nd = normalize3(target - p);
+        att = texture_color(sc, m.texture, u, v);
+        break;
+    }
+    case RT_MAT_METAL: {
+        // metal.rs:21-32
+        d3 refl = normalize3(reflect3(d, n));
+        d3 fz = m.fuzz * uniform_sphere(pp, pixel);
+        no = p + n * pp.bias;
+        nd = normalize3(refl + fz);
+        att = texture_color(sc, m.texture, u, v);
+        break;
+    }
+    case RT_MAT_DIELECTRIC: {
+        // dielectric.rs:25-53
+        bool outside = dot3(d, n) < 0.0;
+        d3 b = n * pp.bias;
+        double kr = fresnel(d, n, m.ior);
+        rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_DIELECTRIC, 0u);
+        d3 fz = m.fuzz * uniform_sphere(pp, pixel);
+        if (rt_rng_u0(&blk) < kr) {
+            nd = normalize3(reflect3(d, n) + fz);
+            no = outside ? p + b : p - b;
+        } else {
+            nd = normalize3(refract(d, n, m.ior) + fz);
+            no = outside ? p - b : p + b;
+        }
+        break;
+    }
+    case RT_MAT_DIFFUSE_LIGHT: {
+        // diffuse_light.rs:19-26 + system.rs:139: emit + background
+        X = m.intensity * texture_color(sc, m.texture, u, v) + bg;
+        return false;
+    }
+    default: {
+        // isotropic.rs:19-26
+        no = p;
+        nd = uniform_sphere(pp, pixel);
+        att = texture_color(sc, m.texture, u, v);
+        break;
+    }
+    }
+    thr = mk3(thr.x * att.x, thr.y * att.y, thr.z * att.z);
+    o = no;
+    d = nd;
+    // the scattered ray has depth + 1; Ray::cast returns the background at max_depth
+    return pp.depth + 1u < pp.max_depth;
+}
+
 __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
                                                      RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
 {
@@ -881,106 +1003,106 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc, RayQueue q
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
         const uint32_t i = base + threadIdx.x;
-        const bool active = i < count;
         bool alive = false;
-        d3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0), thr = mk3(0, 0, 0);
+        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), thr = mk3(0, 0, 0);
         uint32_t slot = 0, pixel = 0;
-        if (active) {
+        if (i < count) {
             slot = qin.slot[i];
             pixel = qin.pixel[i];
             thr = mk3(qin.thr[0][i], qin.thr[1][i], qin.thr[2][i]);
-            int obj = hit.obj[i];
-            d3 X = bg; // what the path sees where it ends
-            bool ended = true;
-            if (obj >= 0) {
-                d3 o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
-                d3 d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
-                double t = hit.t[i];
-                d3 n = mk3(hit.n[0][i], hit.n[1][i], hit.n[2][i]);
-                double u = hit.uv[0][i], v = hit.uv[1][i];
-                const DevMaterial &m = sc.materials[sc.objects[obj].material];
-                d3 p = o + d * t; // RayHit::point (system.rs:173-175)
-                d3 att = mk3(1.0, 1.0, 1.0);
-                switch (m.kind) {
-                case RT_MAT_LAMBERTIAN: {
-                    // lambertian.rs:20-31
-                    no = p + n * pp.bias;
-                    d3 target = p + n + uniform_sphere(pp, pixel);
-                    nd = normalize3(target - p);
-                    att = texture_color(sc, m.texture, u, v);
-                    ended = false;
-                    break;
-                }
-                case RT_MAT_METAL: {
-                    // metal.rs:21-32
-                    d3 refl = normalize3(reflect3(d, n));
-                    d3 fz = m.fuzz * uniform_sphere(pp, pixel);
-                    no = p + n * pp.bias;
-                    nd = normalize3(refl + fz);
-                    att = texture_color(sc, m.texture, u, v);
-                    ended = false;
-                    break;
-                }
-                case RT_MAT_DIELECTRIC: {
-                    // dielectric.rs:25-53
-                    bool outside = dot3(d, n) < 0.0;
-                    d3 b = n * pp.bias;
-                    double kr = fresnel(d, n, m.ior);
-                    rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_DIELECTRIC, 0u);
-                    d3 fz = m.fuzz * uniform_sphere(pp, pixel);
-                    if (rt_rng_u0(&blk) < kr) {
-                        nd = normalize3(reflect3(d, n) + fz);
-                        no = outside ? p + b : p - b;
-                    } else {
-                        nd = normalize3(refract(d, n, m.ior) + fz);
-                        no = outside ? p - b : p + b;
-                    }
-                    ended = false;
-                    break;
-                }
-                case RT_MAT_DIFFUSE_LIGHT: {
-                    // diffuse_light.rs:19-26 + system.rs:139: emit + background
-                    X = m.intensity * texture_color(sc, m.texture, u, v) + bg;
-                    break;
-                }
-                default: {
-                    // isotropic.rs:19-26
-                    no = p;
-                    nd = uniform_sphere(pp, pixel);
-                    att = texture_color(sc, m.texture, u, v);
-                    ended = false;
-                    break;
-                }
-                }
-                if (!ended) {
-                    thr = mk3(thr.x * att.x, thr.y * att.y, thr.z * att.z);
-                    // the scattered ray has depth + 1; Ray::cast returns the background at max_depth
-                    if (pp.depth + 1u >= pp.max_depth) ended = true;
-                }
+            HitRec h;
+            h.obj = hit.obj[i];
+            h.t = 0.0;
+            h.n = mk3(0, 0, 0);
+            h.u = h.v = 0.0;
+            if (h.obj >= 0) {
+                o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
+                d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
+                h.t = hit.t[i];
+                h.n = mk3(hit.n[0][i], hit.n[1][i], hit.n[2][i]);
+                h.u = hit.uv[0][i];
+                h.v = hit.uv[1][i];
             }
-            if (ended) {
+            d3 X;
+            alive = shade_one(sc, o, d, thr, pixel, h, pp, bg, X);
+            if (!alive) {
                 double *px = fb + (size_t)slot * 3;
                 px[0] += thr.x * X.x;
                 px[1] += thr.y * X.y;
                 px[2] += thr.z * X.z;
-            } else {
-                alive = true;
             }
         }
         uint32_t at = block_append(alive, count_out, append_lds);
         if (alive) {
-            qout.o[0][at] = no.x;
-            qout.o[1][at] = no.y;
-            qout.o[2][at] = no.z;
-            qout.d[0][at] = nd.x;
-            qout.d[1][at] = nd.y;
-            qout.d[2][at] = nd.z;
+            qout.o[0][at] = o.x;
+            qout.o[1][at] = o.y;
+            qout.o[2][at] = o.z;
+            qout.d[0][at] = d.x;
+            qout.d[1][at] = d.y;
+            qout.d[2][at] = d.z;
             qout.thr[0][at] = thr.x;
             qout.thr[1][at] = thr.y;
             qout.thr[2][at] = thr.z;
             qout.slot[at] = slot;
             qout.pixel[at] = pixel;
         }
+    }
+}
+
+// The tail of a stratum: once few paths are left, one wave takes one path through all of its
+// remaining segments - nearest hit over the analytic objects (every lane computes the same),
+// the meshes by brute force across the 64 lanes, the material - with no launch per bounce.
+// The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
+// as separate launches.  counts[k] gains one for every ray traced at depth k.
+template <bool CSG, bool MEDIUM, bool TORUS>
+__global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
+                                                    double *fb, PassParams pp, uint32_t *guards_out, int has_mesh)
+{
+    const uint32_t count = counts[pp.depth];
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+    Guards gd;
+    for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
+    gd.overflow = 0u;
+    for (uint32_t i = wave; i < count; i += n_waves) {
+        d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+        d3 thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
+        const uint32_t slot = q.slot[i], pixel = q.pixel[i];
+        PassParams p = pp;
+        for (;;) {
+            HitRec h;
+            bool wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, p, h, gd);
+            if (has_mesh && wants_mesh) {
+                int best_obj = h.obj;
+                double best_t = best_obj >= 0 ? h.t : DBL_MAX;
+                uint32_t best_aux = 0u;
+                if (mesh_brute_wave(sc, o, d, best_obj, best_t, best_aux)) {
+                    h.t = best_t;
+                    h.obj = best_obj;
+                    mesh_hit_surface(sc, o, d, best_obj, best_aux, h.n, h.u, h.v);
+                }
+            }
+            d3 X;
+            const bool alive = shade_one(sc, o, d, thr, pixel, h, p, bg, X);
+            if (!alive) {
+                if (lane_id() == 0u) {
+                    double *px = fb + (size_t)slot * 3;
+                    px[0] += thr.x * X.x;
+                    px[1] += thr.y * X.y;
+                    px[2] += thr.z * X.z;
+                }
+                break;
+            }
+            ++p.depth;
+            if (lane_id() == 0u) atomicAdd(&counts_out[p.depth], 1u);
+        }
+    }
+    if (lane_id() == 0u) { // every lane counted the same events
+        for (int k = 0; k < 5; ++k)
+            if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
+        if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
     }
 }
 
@@ -1054,7 +1176,7 @@ struct rt_scene {
     uint32_t *d_guards = nullptr; // 6
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> evp; // per-pass timing events: [0] before raygen, then 3 per depth
+    std::vector<hipEvent_t> evp; // per-pass timing events: [0] before raygen, then 4 per depth
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -1112,11 +1234,11 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         HIP_TRY(hipMalloc((void **)&s->d_counts, 2 * (max_depth + 2) * sizeof(uint32_t)));
         if (s->h_pinned) (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
-        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (max_depth + 2 + 8) * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (2 * (max_depth + 2) + 8) * sizeof(uint32_t), hipHostMallocDefault));
         s->counts_cap = max_depth + 2;
     }
     if (!s->d_guards) HIP_TRY(hipMalloc((void **)&s->d_guards, 8 * sizeof(uint32_t)));
-    while (s->evp.size() < 1 + 3 * (size_t)max_depth) {
+    while (s->evp.size() < 1 + 4 * (size_t)max_depth) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         s->evp.push_back(e);
@@ -1243,8 +1365,9 @@ static int check_options(const rt_options *o)
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
 // nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the kd-tree pass
-static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
-                             uint32_t *mesh_count, const PassParams &pp, int32_t *ids)
+// returns 1 when the grid walk (k_mesh) ran, 0 otherwise; `mid` is recorded between the two stages
+static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
+                            uint32_t *mesh_count, const PassParams &pp, int32_t *ids, hipEvent_t mid)
 {
     dim3 grid(grid_for(live)), block(RT_BLOCK);
 #define LAUNCH_I(C, M, T)                                                                                              \
@@ -1262,6 +1385,8 @@ static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const R
     default: LAUNCH_I(true, true, true); break;
     }
 #undef LAUNCH_I
+    (void)hipEventRecord(mid, st);
+    int walked = 0;
     if (s->has_mesh) {
         // short queues: one wave per ray over all triangles; long queues: one lane per ray down the kd-tree
         if ((uint64_t)live * s->n_mesh_tris <= (uint64_t)RT_BRUTE_MAX_TESTS) {
@@ -1282,8 +1407,34 @@ static void launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const R
             if (mb > max_wgs) mb = max_wgs;
             hipLaunchKernelGGL(k_mesh, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_lds_bytes, st, s->dev, q,
                                s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES);
+            walked = 1;
         }
     }
+    return walked;
+}
+
+#define RT_TAIL_MAX_TESTS 12000000ull // paths x triangles below which k_tail takes the rest of the stratum (measured)
+
+static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const PassParams &pp, double *d_rgb)
+{
+    uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+#define LAUNCH_T(C, M, T)                                                                                              \
+    hipLaunchKernelGGL((k_tail<C, M, T>), dim3((uint32_t)blocks), dim3(RT_BLOCK), 0, st, s->dev, q, s->d_counts,       \
+                       s->d_counts, d_rgb, pp, s->d_guards, s->has_mesh ? 1 : 0)
+    const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
+    switch (variant) {
+    case 0: LAUNCH_T(false, false, false); break;
+    case 1: LAUNCH_T(false, false, true); break;
+    case 2: LAUNCH_T(false, true, false); break;
+    case 3: LAUNCH_T(false, true, true); break;
+    case 4: LAUNCH_T(true, false, false); break;
+    case 5: LAUNCH_T(true, false, true); break;
+    case 6: LAUNCH_T(true, true, false); break;
+    default: LAUNCH_T(true, true, true); break;
+    }
+#undef LAUNCH_T
 }
 
 typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
@@ -1353,50 +1504,82 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 // count on the device; the bound only sizes grids.  Read-backs cost a stream
                 // synchronisation, so after the first bounces they come every fourth pass.
                 uint32_t live = n_slots;
+                // paths left at which the tail kernel takes over (one wave per path, meshes by brute force)
+                static const uint32_t tail_env = getenv("RT_TAIL_MAX") ? (uint32_t)atoi(getenv("RT_TAIL_MAX")) : 0xFFFFFFFFu;
+                uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 8192u;
+                if (tail_max > 8192u) tail_max = 8192u;
+                if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
                 int cur = 0;
                 uint32_t passes = 0;
+                int tail_at = -1; // depth at which k_tail took over
+                std::vector<uint8_t> walked(opts->max_depth + 1, 0);
                 for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
-                    HIP_TRY(hipEventRecord(s->evp[1 + 3 * depth], st));
-                    launch_intersect(s, st, live, s->q[cur], s->d_counts + depth,
-                                     s->d_counts + (opts->max_depth + 2) + depth, pp, ids);
-                    HIP_TRY(hipEventRecord(s->evp[2 + 3 * depth], st));
+                    HIP_TRY(hipEventRecord(s->evp[1 + 4 * depth], st));
+                    walked[depth] = (uint8_t)launch_intersect(s, st, live, s->q[cur], s->d_counts + depth,
+                                                              s->d_counts + (opts->max_depth + 2) + depth, pp, ids,
+                                                              s->evp[2 + 4 * depth]);
+                    HIP_TRY(hipEventRecord(s->evp[3 + 4 * depth], st));
                     hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, s->q[cur],
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
-                    HIP_TRY(hipEventRecord(s->evp[3 + 3 * depth], st));
-                    local.bounce_passes++;
+                    HIP_TRY(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;
-                    if (depth < 3 || (depth & 3u) == 3u || depth + 1 == opts->max_depth) {
+                    if (depth < 3 || (depth & 3u) == 3u || depth + 1 == opts->max_depth || live <= 8u * tail_max) {
                         HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts + depth + 1, sizeof(uint32_t),
                                                hipMemcpyDeviceToHost, st));
                         HIP_TRY(hipStreamSynchronize(st));
                         live = s->h_pinned[0];
                         RT_TRACE("depth %u live %u", depth, live);
                         if (live == 0) break;
+                        if (live <= tail_max && depth + 1 < opts->max_depth) {
+                            // few paths left: one launch takes them all to their ends
+                            pp.depth = depth + 1;
+                            HIP_TRY(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
+                            launch_tail(s, st, live, s->q[cur], pp, d_rgb);
+                            HIP_TRY(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
+                            tail_at = (int)depth + 1;
+                            break;
+                        }
                     }
                 }
-                HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (opts->max_depth + 1) * sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, 2 * (opts->max_depth + 2) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, st)); // rays per depth, then mesh-queue lengths per depth
                 HIP_TRY(hipStreamSynchronize(st));
-                if (rt_debug()) {
-                    std::vector<uint32_t> mc(opts->max_depth + 1);
-                    (void)hipMemcpy(mc.data(), s->d_counts + (opts->max_depth + 2), mc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-                    for (uint32_t k = 0; k < passes; ++k) RT_TRACE("pass %u: rays %u mesh queue %u", k, s->h_pinned[k], mc[k]);
-                }
+                std::vector<uint32_t> mesh_counts(opts->max_depth + 1, 0u);
+                for (uint32_t k = 0; k <= opts->max_depth; ++k) mesh_counts[k] = s->h_pinned[opts->max_depth + 2 + k];
+                if (rt_debug())
+                    for (uint32_t k = 0; k < passes; ++k)
+                        RT_TRACE("pass %u: rays %u mesh queue %u", k, s->h_pinned[k], mesh_counts[k]);
                 local.primary_rays += s->h_pinned[0];
-                for (uint32_t k = 0; k < opts->max_depth; ++k) local.rays += s->h_pinned[k];
+                for (uint32_t k = 0; k < opts->max_depth; ++k) {
+                    local.rays += s->h_pinned[k];
+                    if (s->h_pinned[k]) local.bounce_passes++;
+                }
                 {
                     float ms_k = 0.f;
                     HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[0], s->evp[1]));
                     local.ms_raygen += ms_k;
                     for (uint32_t k = 0; k < passes; ++k) {
-                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[1 + 3 * k], s->evp[2 + 3 * k]));
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[1 + 4 * k], s->evp[2 + 4 * k]));
                         local.ms_intersect += ms_k;
-                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[2 + 3 * k], s->evp[3 + 3 * k]));
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[2 + 4 * k], s->evp[3 + 4 * k]));
+                        local.ms_mesh += ms_k;
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[3 + 4 * k], s->evp[4 + 4 * k]));
                         local.ms_shade += ms_k;
-                        if (s->h_pinned[k]) local.n_intersect_launches++; // passes that had rays
+                        if (s->h_pinned[k]) {
+                            local.n_intersect_launches++; // passes that had rays
+                            local.intersect_rays += s->h_pinned[k];
+                        }
+                        if (walked[k]) {
+                            local.n_mesh_launches++;
+                            local.mesh_rays += mesh_counts[k];
+                        }
+                    }
+                    if (tail_at >= 0) {
+                        HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[1 + 4 * tail_at], s->evp[2 + 4 * tail_at]));
+                        local.ms_tail += ms_k;
                     }
                 }
             }
@@ -1554,7 +1737,7 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     pp.force_uv = 1;
     pp.bias = 0.0;
     HIP_TRY(hipMemset(s->d_counts + 3, 0, sizeof(uint32_t)));
-    launch_intersect(s, nullptr, n32, s->q[0], s->d_counts, s->d_counts + 3, pp, nullptr);
+    (void)launch_intersect(s, nullptr, n32, s->q[0], s->d_counts, s->d_counts + 3, pp, nullptr, s->evp[2]);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<int32_t> obj(n);
