@@ -39,33 +39,34 @@ BYTES_PER_PIXEL_SAMPLE = 24
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(scene, seconds_hint=20.0):
-    """Time the oracle on the host cores: all-cores row-parallel (reported as
-    cpu_baseline) and single-thread = the reference's own threading at samples=1."""
+def cpu_baseline(scene):
+    """Time the oracle on the host cores on a bounded sample of the bench workload:
+    the whole 4K frame row-parallel over all cores (reported as cpu_baseline) and a
+    1/16-size frame on one thread = the reference's own threading at samples=1."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import raytracer_amd as rt
-    w, h = WIDTH // 4, HEIGHT // 4
-    o = rt.Options(width=w, height=h, samples=SAMPLES, seed=1)
-    sc = rt.parse_file(o, os.path.join(ROOT, "tests", "assets", "scenes", scene + ".scene"),
-                       os.path.join(ROOT, "tests", "assets"))
+    path = os.path.join(ROOT, "tests", "assets", "scenes", scene + ".scene")
+    assets = os.path.join(ROOT, "tests", "assets")
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    w, h = WIDTH, HEIGHT
+    o = rt.Options(width=w, height=h, samples=SAMPLES, seed=1)
+    sc = rt.parse_file(o, path, assets)
     t0 = time.perf_counter()
     _, _, st = oracle_lib.render(sc.desc, o.to_c(), threads=cores, want_ids=False)
     t_all = time.perf_counter() - t0
-    # single thread on a quarter of that sample again (rows scale linearly)
-    o1 = rt.Options(width=w // 2, height=h // 2, samples=SAMPLES, seed=1)
-    sc1 = rt.parse_file(o1, os.path.join(ROOT, "tests", "assets", "scenes", scene + ".scene"),
-                        os.path.join(ROOT, "tests", "assets"))
+    w1, h1 = WIDTH // 4, HEIGHT // 4
+    o1 = rt.Options(width=w1, height=h1, samples=SAMPLES, seed=1)
+    sc1 = rt.parse_file(o1, path, assets)
     t0 = time.perf_counter()
     _, _, st1 = oracle_lib.render(sc1.desc, o1.to_c(), threads=1, want_ids=False)
     t_one = time.perf_counter() - t0
     return ({"value": st.rays / t_all / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-             "sample": "%s.scene %dx%d samples=%d seed=1, oracle/liboracle.so row-parallel over %d threads, %.1f s"
-                       % (scene, w, h, SAMPLES, cores, t_all)},
+             "sample": "%s.scene %dx%d samples=%d seed=1 (one whole bench frame, %d rays), oracle/liboracle.so "
+                       "row-parallel over %d threads, %.1f s" % (scene, w, h, SAMPLES, st.rays, cores, t_all)},
             {"value": st1.rays / t_one / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
              "sample": "%s.scene %dx%d samples=%d seed=1, one thread (the reference parallelises over strata only), %.1f s"
-                       % (scene, w // 2, h // 2, SAMPLES, t_one)})
+                       % (scene, w1, h1, SAMPLES, t_one)})
 
 
 def main():
