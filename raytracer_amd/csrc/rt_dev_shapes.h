@@ -708,18 +708,20 @@ RT_DEV bool tri_hit(const double *__restrict__ tr, d3 o, d3 d, double &t, double
 }
 
 // bounding_box.rs:13-44 against the Mesh::new box (which contains the origin)
-RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
+RT_DEV bool box_hit(const double *qmin, const double *qmax, d3 o, d3 inv);
+RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv) { return box_hit(m.qmin, m.qmax, o, inv); }
+RT_DEV bool box_hit(const double *qmin, const double *qmax, d3 o, d3 inv)
 {
     int sx = inv.x < 0.0, sy = inv.y < 0.0, sz = inv.z < 0.0;
-    double tmin = ((sx ? m.qmax[0] : m.qmin[0]) - o.x) * inv.x;
-    double tmax = ((sx ? m.qmin[0] : m.qmax[0]) - o.x) * inv.x;
-    double tymin = ((sy ? m.qmax[1] : m.qmin[1]) - o.y) * inv.y;
-    double tymax = ((sy ? m.qmin[1] : m.qmax[1]) - o.y) * inv.y;
+    double tmin = ((sx ? qmax[0] : qmin[0]) - o.x) * inv.x;
+    double tmax = ((sx ? qmin[0] : qmax[0]) - o.x) * inv.x;
+    double tymin = ((sy ? qmax[1] : qmin[1]) - o.y) * inv.y;
+    double tymax = ((sy ? qmin[1] : qmax[1]) - o.y) * inv.y;
     if ((tmin > tymax) || (tymin > tmax)) return false;
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
-    double tzmin = ((sz ? m.qmax[2] : m.qmin[2]) - o.z) * inv.z;
-    double tzmax = ((sz ? m.qmin[2] : m.qmax[2]) - o.z) * inv.z;
+    double tzmin = ((sz ? qmax[2] : qmin[2]) - o.z) * inv.z;
+    double tzmax = ((sz ? qmin[2] : qmax[2]) - o.z) * inv.z;
     if ((tmin > tzmax) || (tzmin > tmax)) return false;
     return true;
 }
@@ -730,25 +732,27 @@ RT_DEV bool mesh_box_hit(const DevMesh &m, d3 o, d3 inv)
 #define RT_MESH_LANES 256 // = threads per k_mesh workgroup
 
 // clip the ray against the tight (padded) bounds of the mesh
-RT_DEV bool mesh_clip(const DevMesh &m, d3 o, d3 inv, double &t0, double &t1)
+RT_DEV bool box_clip(const double *bmin, const double *bmax, d3 o, d3 inv, double &t0, double &t1)
 {
     t0 = 0.0;
     t1 = 1.0e300;
     double lo, hi;
-    lo = (m.bmin[0] - o.x) * inv.x;
-    hi = (m.bmax[0] - o.x) * inv.x;
+    lo = (bmin[0] - o.x) * inv.x;
+    hi = (bmax[0] - o.x) * inv.x;
     if (lo > hi) { double s = lo; lo = hi; hi = s; }
     if (lo == lo && lo > t0) t0 = lo;
     if (hi == hi && hi < t1) t1 = hi;
-    lo = (m.bmin[1] - o.y) * inv.y;
-    hi = (m.bmax[1] - o.y) * inv.y;
+    lo = (bmin[1] - o.y) * inv.y;
+    hi = (bmax[1] - o.y) * inv.y;
     if (lo > hi) { double s = lo; lo = hi; hi = s; }
     if (lo == lo && lo > t0) t0 = lo;
     if (hi == hi && hi < t1) t1 = hi;
-    lo = (m.bmin[2] - o.z) * inv.z;
-    hi = (m.bmax[2] - o.z) * inv.z;
+    lo = (bmin[2] - o.z) * inv.z;
+    hi = (bmax[2] - o.z) * inv.z;
     if (lo > hi) { double s = lo; lo = hi; hi = s; }
     if (lo == lo && lo > t0) t0 = lo;
     if (hi == hi && hi < t1) t1 = hi;
     return !(t0 > t1);
 }
+
+RT_DEV bool mesh_clip(const DevMesh &m, d3 o, d3 inv, double &t0, double &t1) { return box_clip(m.bmin, m.bmax, o, inv, t0, t1); }

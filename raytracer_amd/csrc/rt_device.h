@@ -102,6 +102,24 @@ struct DevMesh {
     double cell[3], inv_cell[3];
 };
 
+// One (mesh object, mesh) pair, in the order Ray::trace / Composite::intersect would visit them:
+// everything k_mesh needs to start the walk of one mesh and to finish a hit, in one record (the
+// walking waves read it from LDS instead of chasing objects -> leaves -> meshes through memory).
+struct DevMeshJob {
+    int32_t object;   // index in the object list
+    int32_t mesh;     // index within the object (Composite child order)
+    int32_t identity; // the object's frame maps are the identity
+    uint32_t smooth;
+    uint32_t n[3];
+    uint32_t bits0, cell0, dist0;
+    uint32_t tri0;    // into tris / tri_nrm
+    uint32_t pad;
+    DevXform W, O;    // the object's frame: world -> object, object -> world
+    double qmin[3], qmax[3];
+    double bmin[3], bmax[3];
+    double inv_cell[3];
+};
+
 struct DevMaterial {
     int32_t kind;
     int32_t texture;
@@ -126,6 +144,8 @@ struct DevScene {
     const double *tris;      // 9 per triangle
     const double *cell_tris; // 10 per (cell, triangle) reference, in cell order: the 9 above + the triangle index (low word)
     const uint32_t *tri_n; // 3 per triangle (normal indices, mesh-relative)
+    const double *tri_nrm; // 9 per triangle: its three vertex normals
+    const DevMeshJob *jobs;
     const double *normals; // xyz
     const DevMaterial *materials;
     const DevTexture *textures;
@@ -134,6 +154,8 @@ struct DevScene {
     uint32_t n_grid_words; // (bits, rank) pairs in grid_bits
     uint32_t n_cell_starts; // entries in cell_start
     uint32_t n_dist_words;  // words in grid_dist
+    uint32_t n_jobs;
+    uint32_t pad2;
     double background[3];
     double cam_fov_factor;
     double cam_c2w[16];
@@ -145,3 +167,4 @@ struct DevScene {
 #define DEV_GRID_MAX_WORDS 2048 // occupancy words of all meshes together: 16 KB of LDS with their ranks, 32 KB of distances
 #define DEV_GRID_MAX_STARTS 6144 // cell_start entries kept in LDS (24 KB); beyond that they are read from memory
 #define DEV_GRID_MAX_AXIS 255
+#define DEV_MESH_JOBS_LDS 16 // job records kept in LDS (beyond that they are read from memory)

@@ -565,6 +565,43 @@ int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
         if (desc->n_image_bytes) out.image_data.assign(desc->image_data, desc->image_data + desc->n_image_bytes);
         if (desc->n_normals) out.normals.assign(desc->normals, desc->normals + 3 * (size_t)desc->n_normals);
         for (uint32_t k = 0; k < desc->n_objects; ++k) f.emit_object(desc->objects[k]);
+        // per-triangle vertex normals and the (object, mesh) job records of k_mesh
+        for (size_t k = 0; k < out.objects.size(); ++k) {
+            const DevObject &ob = out.objects[k];
+            if (ob.kind != DO_MESH) continue;
+            for (int mi = 0; mi < ob.n_meshes; ++mi) {
+                const DevMesh &m = out.meshes[ob.mesh0 + mi];
+                const DevLeaf &F = out.leaves[ob.frame];
+                DevMeshJob j;
+                std::memset(&j, 0, sizeof(j));
+                j.object = (int32_t)k;
+                j.mesh = mi;
+                j.identity = F.identity;
+                j.smooth = m.smooth;
+                for (int a = 0; a < 3; ++a) {
+                    j.n[a] = m.n[a];
+                    j.qmin[a] = m.qmin[a];
+                    j.qmax[a] = m.qmax[a];
+                    j.bmin[a] = m.bmin[a];
+                    j.bmax[a] = m.bmax[a];
+                    j.inv_cell[a] = m.inv_cell[a];
+                }
+                j.bits0 = m.bits0;
+                j.cell0 = m.cell0;
+                j.dist0 = m.dist0;
+                j.tri0 = m.tri0;
+                j.W = F.W;
+                j.O = F.O;
+                out.jobs.push_back(j);
+                if (out.tri_nrm.size() < ((size_t)m.tri0 + m.n_tris) * 9) out.tri_nrm.resize(((size_t)m.tri0 + m.n_tris) * 9, 0.0);
+                for (uint32_t t = 0; t < m.n_tris; ++t)
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t ni = out.tri_n[((size_t)m.tri0 + t) * 3 + c];
+                        for (int a = 0; a < 3; ++a)
+                            out.tri_nrm[((size_t)m.tri0 + t) * 9 + c * 3 + a] = out.normals[((size_t)m.normal0 + ni) * 3 + a];
+                    }
+            }
+        }
         for (int k = 0; k < 3; ++k) out.background[k] = desc->background[k];
         out.cam_fov_factor = desc->camera.fov_factor;
         std::memcpy(out.cam_c2w, desc->camera.camera_to_world, sizeof(out.cam_c2w));

@@ -19,6 +19,8 @@ struct FlatScene {
     std::vector<double> tris;
     std::vector<double> cell_tris;
     std::vector<uint32_t> tri_n;
+    std::vector<double> tri_nrm;
+    std::vector<DevMeshJob> jobs;
     std::vector<double> normals;
     std::vector<DevMaterial> materials;
     std::vector<DevTexture> textures;

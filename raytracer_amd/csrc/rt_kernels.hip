@@ -52,6 +52,9 @@ struct HitBuf {
     int32_t *obj;
 };
 
+#ifndef RT_MESH_BATCH
+#define RT_MESH_BATCH 2
+#endif
 #ifndef RT_MESH_WAVES
 #define RT_MESH_WAVES 3
 #endif
@@ -461,6 +464,9 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
 //
 // Waves take blocks of 64 queue entries, interleaved; with more than one block per
 // wave (large queues) a wave refills its finished lanes once `refill` of them are idle.
+#ifdef RT_MESH_PROF
+__device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, services, lanes walking, lanes testing, waves
+#endif
 // The walk state is kept in plain scalars (not an aggregate): selecting a field by axis
 // would otherwise be compiled into an indexed access to a copy in scratch memory.
 #define WALK_LOCATE_AXIS(OG, DG, IG, N, C, TM)                                                                         \
@@ -507,11 +513,17 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                                                       const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
                                                       uint32_t refill, uint32_t block_arg, uint32_t resident_waves)
 {
-    extern __shared__ uint2 grid_lds[]; // (bits, rank) pairs, distance words, then the cell starts if they fit
+    extern __shared__ double4 mesh_lds[]; // job records, (bits, rank) pairs, distance words, then the cell starts if they fit
+    const uint32_t n_jobs_lds = sc.n_jobs < DEV_MESH_JOBS_LDS ? sc.n_jobs : DEV_MESH_JOBS_LDS;
+    DevMeshJob *jobs_lds = reinterpret_cast<DevMeshJob *>(mesh_lds);
+    uint2 *grid_lds = reinterpret_cast<uint2 *>(jobs_lds + n_jobs_lds);
     uint32_t *dist_lds = reinterpret_cast<uint32_t *>(grid_lds + sc.n_grid_words);
     uint32_t *starts_lds = dist_lds + sc.n_dist_words;
     const bool starts_in_lds = sc.n_cell_starts <= DEV_GRID_MAX_STARTS;
     {
+        const uint32_t *jw = reinterpret_cast<const uint32_t *>(sc.jobs);
+        uint32_t *jl = reinterpret_cast<uint32_t *>(jobs_lds);
+        for (uint32_t i = threadIdx.x; i < n_jobs_lds * (uint32_t)(sizeof(DevMeshJob) / 4); i += blockDim.x) jl[i] = jw[i];
         const uint2 *gw = reinterpret_cast<const uint2 *>(sc.grid_bits);
         for (uint32_t i = threadIdx.x; i < sc.n_grid_words; i += blockDim.x) grid_lds[i] = gw[i];
         for (uint32_t i = threadIdx.x; i < sc.n_dist_words; i += blockDim.x) dist_lds[i] = sc.grid_dist[i];
@@ -519,6 +531,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
             for (uint32_t i = threadIdx.x; i < sc.n_cell_starts; i += blockDim.x) starts_lds[i] = sc.cell_start[i];
     }
     __syncthreads();
+// job record `J` (an index): from LDS when it is one of the first DEV_MESH_JOBS_LDS
+#define JOB(J) (*((J) < (int)n_jobs_lds ? (const DevMeshJob *)(jobs_lds + (J)) : (sc.jobs + (J))))
 
     // every wave takes blocks of 64 queue entries, interleaved with the other waves: neighbouring
     // rays cost about the same, so contiguous chunks would leave whole waves with the expensive ones
@@ -534,6 +548,9 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
         block = 16u;
         while (block < 64u && (uint64_t)block * spread < count) block <<= 1;
     }
+    // a wave with a single block has nothing to refill from: it services its lanes twice, to load
+    // the block and to store the results once every lane is done
+    if ((uint64_t)n_waves * block >= count) refill = 65u;
     uint64_t cursor = (uint64_t)wave * block; // next queue entry of this wave
     uint64_t block_end = cursor + block;      // end of its current block
 
@@ -541,13 +558,15 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     bool active = false, have_ray = false;
     uint32_t ri = 0;
     d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1); // ray in the current object's space
-    int k = -1, mi = 0;
+    int jb = -1;                           // current job = (object, mesh) pair
+    int best_job = -1;                     // job of the nearest mesh hit
     double best_t = 0.0, wbound = 0.0; // nearest world hit so far; the same as a bound in object space
     int best_obj = -1;
     uint32_t best_aux = 0u;
     bool replaced = false;
     double obj_t = 0.0;
     uint32_t obj_aux = 0u;
+    int obj_job = -1;
     bool obj_found = false;
     // walk state: grid-space origin, direction, 1 / direction; ray parameter at the next cell
     // boundary per axis; where the current cell was entered; where the walk ends
@@ -558,6 +577,13 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     double mt = 1.0e300;
     uint32_t mtri = 0xFFFFFFFFu;
 
+#ifdef RT_MESH_PROF
+    long long pf_t = clock64(), pf_service = 0, pf_walk = 0, pf_test = 0, pf_n = 0, pf_a = 0, pf_b = 0, pf_c = 0, pf_d = 0;
+    unsigned long long pf_rounds = 0, pf_services = 0, pf_lanes_walk = 0, pf_lanes_test = 0, pf_tests = 0;
+#define PF_MARK(ACC) do { long long n_ = clock64(); ACC += n_ - pf_t; pf_t = n_; } while (0)
+#else
+#define PF_MARK(ACC) do { } while (0)
+#endif
     for (;;) {
         // ---------------------------------------------------------------- service finished lanes
         const bool wants = !active && (have_ray || (cursor < count && lane_id() < block));
@@ -573,11 +599,13 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                 // result of the walk that just ended: min_by keeps the first minimum
                 if (mtri != 0xFFFFFFFFu && (!obj_found || mt < obj_t)) {
                     obj_t = mt;
-                    obj_aux = ((uint32_t)mi << 24) | (mtri & 0xFFFFFFu);
+                    obj_aux = mtri;
+                    obj_job = jb;
                     obj_found = true;
                 }
                 advance = true;
             }
+            PF_MARK(pf_a);
             const bool takes = !active && !have_ray && lane_id() < block;
             const uint64_t empty = __ballot(takes);
             if (takes) {
@@ -591,8 +619,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     best_aux = 0u;
                     replaced = false;
                     have_ray = true;
-                    k = -1;
-                    mi = 0;
+                    jb = -1;
                     obj_found = false;
                     advance = true;
                 }
@@ -602,82 +629,119 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                 cursor = block_end + (uint64_t)(n_waves - 1u) * block;
                 block_end = cursor + block;
             }
+            PF_MARK(pf_b);
             if (advance) {
-                // next (object, mesh) whose boxes the ray passes; closing an object merges its
+                // next (object, mesh) job whose boxes the ray passes; leaving an object merges its
                 // nearest triangle into the ray's hit
                 bool found = false;
                 for (int guard = 0; guard < 1 << 20; ++guard) {
-                    if (k >= 0) ++mi;
-                    if (k < 0 || mi >= sc.objects[k].n_meshes) {
-                        if (k >= 0 && obj_found) {
-                            const DevLeaf &F = sc.leaves[sc.objects[k].frame];
-                            LeafRay ry;
-                            ry.o = o;
-                            ry.d = d;
-                            double tw = leaf_t_to_world(F, wo, ry, obj_t);
+                    const int prev_obj = jb >= 0 ? JOB(jb).object : -1;
+                    ++jb;
+                    const int next_obj = jb < (int)sc.n_jobs ? JOB(jb).object : -2;
+                    if (next_obj != prev_obj) {
+                        if (prev_obj >= 0 && obj_found) {
+                            const DevMeshJob &P = JOB(jb - 1);
+                            double tw = obj_t; // Intersection::to_world's t (system.rs:190-195)
+                            if (!P.identity) tw = signum(obj_t) * len3(xf_point(P.O, o + d * obj_t) - wo);
                             if (tw >= 0.0 && tw < DBL_MAX &&
-                                (best_obj < 0 || tw < best_t || (tw == best_t && k < best_obj))) {
+                                (best_obj < 0 || tw < best_t || (tw == best_t && prev_obj < best_obj))) {
                                 best_t = tw;
-                                best_obj = k;
+                                best_obj = prev_obj;
                                 best_aux = obj_aux;
+                                best_job = obj_job;
                                 replaced = true;
                             }
                         }
-                        ++k;
-                        while (k < sc.n_objects && sc.objects[k].kind != DO_MESH) ++k;
-                        if (k >= sc.n_objects) break;
-                        const DevLeaf &F = sc.leaves[sc.objects[k].frame];
-                        LeafRay ry = to_leaf(F, wo, wd);
-                        o = ry.o;
-                        d = ry.d;
-                        // a hit farther than the nearest one so far cannot win: object-space distance
-                        // = world distance * |W d|; the slack keeps exact ties in play
-                        const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, wd));
+                        if (next_obj < 0) break;
+                        const DevMeshJob &J = JOB(jb);
+                        // Ray::transform (system.rs:145-152); a hit farther than the nearest one so far
+                        // cannot win: object-space distance = world distance * |W d|; slack keeps ties
+                        double scale = 1.0;
+                        if (J.identity) {
+                            o = wo;
+                            d = wd;
+                        } else {
+                            o = xf_point(J.W, wo);
+                            const d3 dl = xf_dir(J.W, wd);
+                            scale = len3(dl);
+                            d = normalize3(dl);
+                        }
                         wbound = best_obj >= 0 ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
                         obj_found = false;
-                        mi = 0;
                     }
-                    const DevMesh &m = sc.meshes[sc.objects[k].mesh0 + mi];
+                    const DevMeshJob &J = JOB(jb);
                     const d3 inv = mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                    if (!mesh_box_hit(m, o, inv)) continue;
+                    if (!box_hit(J.qmin, J.qmax, o, inv)) continue;
                     double t0, t1;
-                    if (!mesh_clip(m, o, inv, t0, t1)) continue;
+                    if (!box_clip(J.bmin, J.bmax, o, inv, t0, t1)) continue;
                     if (wbound < t1) t1 = wbound;
                     if (obj_found && obj_t < t1) t1 = obj_t; // a later mesh must be strictly nearer
                     if (t0 > t1) continue;
                     // enter the grid at t0
-                    ogx = (o.x - m.bmin[0]) * m.inv_cell[0];
-                    ogy = (o.y - m.bmin[1]) * m.inv_cell[1];
-                    ogz = (o.z - m.bmin[2]) * m.inv_cell[2];
-                    dgx = d.x * m.inv_cell[0];
-                    dgy = d.y * m.inv_cell[1];
-                    dgz = d.z * m.inv_cell[2];
+                    ogx = (o.x - J.bmin[0]) * J.inv_cell[0];
+                    ogy = (o.y - J.bmin[1]) * J.inv_cell[1];
+                    ogz = (o.z - J.bmin[2]) * J.inv_cell[2];
+                    dgx = d.x * J.inv_cell[0];
+                    dgy = d.y * J.inv_cell[1];
+                    dgz = d.z * J.inv_cell[2];
                     igx = 1.0 / dgx;
                     igy = 1.0 / dgy;
                     igz = 1.0 / dgz;
-                    nx = m.n[0];
-                    ny = m.n[1];
-                    nz = m.n[2];
+                    nx = J.n[0];
+                    ny = J.n[1];
+                    nz = J.n[2];
                     w_tc = t0;
                     t_end = t1;
-                    bits0 = m.bits0;
-                    cell0 = m.cell0;
-                    dist0 = m.dist0;
+                    bits0 = J.bits0;
+                    cell0 = J.cell0;
+                    dist0 = J.dist0;
                     WALK_LOCATE();
                     mt = 1.0e300;
                     mtri = 0xFFFFFFFFu;
                     found = true;
                     break;
                 }
+                PF_MARK(pf_c);
                 if (found) {
                     active = true;
                 } else {
-                    if (replaced) write_mesh_hit(sc, q, hit, primary_ids, ri, wo, wd, best_t, best_obj, best_aux);
+                    if (replaced) {
+                        // normal / uv of the hit (mesh.rs:97-112 + the Composite's to_world)
+                        const DevMeshJob &B = JOB(best_job);
+                        d3 bo = wo, bd = wd;
+                        if (!B.identity) {
+                            bo = xf_point(B.W, wo);
+                            bd = normalize3(xf_dir(B.W, wd));
+                        }
+                        const size_t tr = (size_t)B.tri0 + best_aux;
+                        const double *nb = sc.tri_nrm + tr * 9;
+                        const d3 n0 = mk3(nb[0], nb[1], nb[2]), n1 = mk3(nb[3], nb[4], nb[5]), n2 = mk3(nb[6], nb[7], nb[8]);
+                        double tt = 0.0, u = 0.0, v = 0.0;
+                        tri_hit(sc.tris + tr * 9, bo, bd, tt, u, v);
+                        d3 nl = B.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
+                        d3 n = B.identity ? nl : normalize3(xf_normal(B.W, nl));
+                        hit.t[ri] = best_t;
+                        hit.n[0][ri] = n.x;
+                        hit.n[1][ri] = n.y;
+                        hit.n[2][ri] = n.z;
+                        hit.uv[0][ri] = u;
+                        hit.uv[1][ri] = v;
+                        hit.obj[ri] = best_obj;
+                        if (primary_ids) primary_ids[q.slot[ri]] = best_obj;
+                    }
                     have_ray = false;
                 }
             }
+            PF_MARK(pf_d);
+#ifdef RT_MESH_PROF
+            ++pf_services;
+#endif
             continue; // re-evaluate: lanes whose new ray needed no walk can be filled again
         }
+#ifdef RT_MESH_PROF
+        ++pf_rounds;
+        pf_lanes_walk += __popcll(__ballot(active));
+#endif
 
         // ---------------------------------------------------------------- walk to the next occupied cell
         // "while-while": all lanes first move to their next occupied cell (LDS only), then the wave
@@ -710,8 +774,15 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     }
                 }
             }
+            PF_MARK(pf_walk);
+#ifdef RT_MESH_PROF
+            pf_lanes_test += __popcll(__ballot(active && occupied));
+#endif
             if (active && occupied) {
                 const uint2 gw = grid_lds[bits0 + (cell >> 5)];
+#ifdef RT_MESH_PROF
+                pf_tests += 0; // counted below per lane
+#endif
                 const uint32_t r = cell0 + gw.y + (uint32_t)__popc(gw.x & ((1u << (cell & 31u)) - 1u));
                 uint32_t first, last;
                 if (starts_in_lds) {
@@ -721,21 +792,28 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     first = sc.cell_start[r];
                     last = sc.cell_start[r + 1u];
                 }
-                // one record ahead: the loads of the next triangle are in flight during the test of this one
+                // RT_MESH_BATCH records per step, all loaded before the first test: a step costs one
+                // round trip to memory (~2000 cycles for 64 lanes' scattered records) whatever it tests
                 const double2 *__restrict__ rec = reinterpret_cast<const double2 *>(sc.cell_tris + (size_t)first * 10);
-                double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
-                for (uint32_t e = first; e < last; ++e) {
-                    const d3 v0 = mk3(r0.x, r0.y, r1.x), e1 = mk3(r1.y, r2.x, r2.y), e2 = mk3(r3.x, r3.y, r4.x);
-                    const uint32_t ti = (uint32_t)__double2loint(r4.y);
-                    if (e + 1u < last) {
-                        rec += 5;
-                        r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+                for (uint32_t e = first; e < last; e += RT_MESH_BATCH, rec += 5 * RT_MESH_BATCH) {
+                    double2 r[RT_MESH_BATCH][5];
+#pragma unroll
+                    for (int b = 0; b < RT_MESH_BATCH; ++b) {
+                        const double2 *src = (e + (uint32_t)b < last) ? rec + 5 * b : rec; // past the end: repeat the first
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) r[b][c] = src[c];
                     }
-                    double t, u, v;
-                    if (tri_hit_v(v0, e1, e2, o, d, t, u, v)) {
-                        if (t < mt || (t == mt && ti < mtri)) {
-                            mt = t;
-                            mtri = ti;
+#pragma unroll
+                    for (int b = 0; b < RT_MESH_BATCH; ++b) {
+                        const d3 v0 = mk3(r[b][0].x, r[b][0].y, r[b][1].x), e1 = mk3(r[b][1].y, r[b][2].x, r[b][2].y),
+                                 e2 = mk3(r[b][3].x, r[b][3].y, r[b][4].x);
+                        const uint32_t ti = (uint32_t)__double2loint(r[b][4].y);
+                        double t, u, v;
+                        if (tri_hit_v(v0, e1, e2, o, d, t, u, v)) {
+                            if (t < mt || (t == mt && ti < mtri)) { // a repeated record cannot beat itself
+                                mt = t;
+                                mtri = ti;
+                            }
                         }
                     }
                 }
@@ -746,7 +824,24 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                 if (!ok) active = false;
             }
         }
+        PF_MARK(pf_test);
     }
+#ifdef RT_MESH_PROF
+    if (lane_id() == 0) {
+        atomicAdd(&g_pf[0], (unsigned long long)(pf_a + pf_b + pf_c + pf_d));
+        atomicAdd(&g_pf[8], (unsigned long long)pf_a);
+        atomicAdd(&g_pf[9], (unsigned long long)pf_b);
+        atomicAdd(&g_pf[10], (unsigned long long)pf_c);
+        atomicAdd(&g_pf[11], (unsigned long long)pf_d);
+        atomicAdd(&g_pf[1], (unsigned long long)pf_walk);
+        atomicAdd(&g_pf[2], (unsigned long long)pf_test);
+        atomicAdd(&g_pf[3], pf_rounds);
+        atomicAdd(&g_pf[4], pf_services);
+        atomicAdd(&g_pf[5], pf_lanes_walk);
+        atomicAdd(&g_pf[6], pf_lanes_test);
+        atomicAdd(&g_pf[7], 1ull);
+    }
+#endif
 }
 
 // The same merge for a short queue: one wave per ray, every lane testing its share of the
@@ -1290,9 +1385,13 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     if ((rc = upload(s, flat.cell_start, &s->dev.cell_start))) return fail(rc);
     s->dev.n_grid_words = (uint32_t)(flat.grid_bits.size() / 2);
     if ((rc = upload(s, flat.grid_dist, &s->dev.grid_dist))) return fail(rc);
+    if ((rc = upload(s, flat.tri_nrm, &s->dev.tri_nrm))) return fail(rc);
+    if ((rc = upload(s, flat.jobs, &s->dev.jobs))) return fail(rc);
     s->dev.n_cell_starts = (uint32_t)flat.cell_start.size();
     s->dev.n_dist_words = (uint32_t)flat.grid_dist.size();
-    s->mesh_lds_bytes = s->dev.n_grid_words * 8u + s->dev.n_dist_words * 4u +
+    s->dev.n_jobs = (uint32_t)flat.jobs.size();
+    s->mesh_lds_bytes = (uint32_t)(std::min<size_t>(flat.jobs.size(), DEV_MESH_JOBS_LDS) * sizeof(DevMeshJob)) +
+                        s->dev.n_grid_words * 8u + s->dev.n_dist_words * 4u +
                         (s->dev.n_cell_starts <= DEV_GRID_MAX_STARTS ? s->dev.n_cell_starts * 4u : 0u);
     if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
     if ((rc = upload(s, flat.cell_tris, &s->dev.cell_tris))) return fail(rc);
@@ -1602,6 +1701,19 @@ finished:
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
     local.interval_overflow = s->h_pinned[5];
+#ifdef RT_MESH_PROF
+    {
+        unsigned long long pf[12];
+        (void)hipMemcpyFromSymbol(pf, HIP_SYMBOL(g_pf), sizeof(pf));
+        fprintf(stderr, "[k_mesh] waves %llu: cycles/wave service %.0f walk %.0f test %.0f; rounds/wave %.1f services/wave %.1f; lanes walking/round %.1f testing/round %.1f\n",
+                pf[7], (double)pf[0] / pf[7], (double)pf[1] / pf[7], (double)pf[2] / pf[7], (double)pf[3] / pf[7],
+                (double)pf[4] / pf[7], (double)pf[5] / (double)pf[3], (double)pf[6] / (double)pf[3]);
+        fprintf(stderr, "[k_mesh] service split: reload+merge %.0f fetch %.0f advance %.0f write %.0f\n", (double)pf[8] / pf[7],
+                (double)pf[9] / pf[7], (double)pf[10] / pf[7], (double)pf[11] / pf[7]);
+        unsigned long long z[12] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf), z, sizeof(z));
+    }
+#endif
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     local.ms_device = ms;
