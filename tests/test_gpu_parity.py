@@ -59,6 +59,19 @@ def test_csg_without_torus_is_exact(rt):
     assert np.allclose(rgb, ref, rtol=1e-9, atol=1e-12)
 
 
+def test_several_meshes_and_mesh_objects(rt):
+    """Two mesh objects, one of them an OBJ with two `o` groups (a Composite of two Meshes that
+    overlap), with transforms, a metal and a glass material around them: the (object, mesh) job
+    order of k_mesh, the early-out bounds between meshes and the tail kernel with several meshes."""
+    o = rt.Options(width=240, height=180, samples=4, seed=11)
+    sc = rt.parse_file(o, parity.scene_path("meshes2"), parity.ASSETS)
+    assert sc.desc.contents.n_meshes == 3
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert {1, 2, 3, 4} <= set(np.unique(rids).tolist())      # floor, both mesh objects, the glass ball
+    _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
+
+
 def test_plumbing_config_three_spheres_640x480(rt):
     """BASELINE configs[0]: three-spheres at 640x480, samples=1, seed 1."""
     o = rt.Options(width=640, height=480, samples=1, seed=1)
