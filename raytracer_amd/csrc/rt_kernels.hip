@@ -3,7 +3,7 @@
 //
 // One stratum of one shard = one wavefront run:
 //
-//   k_raygen      camera + jitter                        (system.rs:237-242, 57-66)
+//   (primary rays: camera + jitter, system.rs:237-242, 57-66, regenerated inside the depth-0 kernels)
 //   repeat for depth = 0 .. max_depth-1 while rays remain:
 //     k_intersect nearest hit over the object list        (system.rs:122-133, shapes/*)
 //     k_shade     emit / scatter / terminate, compacting  (system.rs:112-120,135-142,
@@ -43,6 +43,13 @@ struct RayQueue {
     double *thr[3];
     uint32_t *slot;  // index into the shard's frame buffer
     uint32_t *pixel; // y * width + x, the random-number key
+    // primary != 0: nothing above is read.  Entry i is slot i of the shard and its ray is that
+    // pixel's camera ray, regenerated wherever it is needed (a jitter draw and a normalise) instead
+    // of being written by one kernel and read back by three: 1.8 GB less traffic per 4K frame.
+    int primary;
+    uint32_t rank, s_i, s_j;
+    rt_shard_geom g;
+    double recip_sqrt_spp;
 };
 
 struct HitBuf {
@@ -105,48 +112,44 @@ RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
 #define RT_BLOCK_WIDE 1024 // ray generation and shading: light on registers, heavy on queue appends
 
 // ------------------------------------------------------------------ ray generation
-__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_raygen(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots,
-                                                      uint32_t s_i, uint32_t s_j, double recip_sqrt_spp, PassParams pp,
-                                                      RayQueue q, uint32_t *count)
+// get_stratified_ray + Camera::pixel_ray (system.rs:237-242, 57-66) for slot `slot` of the shard;
+// false for the padding slots beyond the image edge
+RT_DEV bool primary_ray(const DevScene &sc, const RayQueue &q, const PassParams &pp, uint32_t slot, d3 &origin, d3 &dir,
+                        uint32_t &pixel)
 {
-    __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n_slots; base += stride) {
-        uint32_t slot = base + threadIdx.x;
-        uint32_t x = 0, y = 0;
-        bool valid = slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y);
-        uint32_t at = block_append(valid, count, append_lds);
-        if (!valid) continue;
-        uint32_t pixel = y * g.width + x;
-        // get_stratified_ray (system.rs:237-242)
-        rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, 0u, RT_RNG_SITE_JITTER, 0u);
-        double sx = (((double)s_i + rt_rng_u0(&blk)) * recip_sqrt_spp) - 0.5;
-        double sy = (((double)s_j + rt_rng_u1(&blk)) * recip_sqrt_spp) - 0.5;
-        double px = (double)x + sx, py = (double)y + sy;
-        // Camera::pixel_ray (system.rs:57-66)
-        double w = (double)g.width, h = (double)g.height;
-        double aspect = w / h;
-        double ndcx = px / w, ndcy = py / h;
-        double cx = (2.0 * ndcx - 1.0) * sc.cam_fov_factor * aspect;
-        double cy = (1.0 - 2.0 * ndcy) * sc.cam_fov_factor;
-        const double *m = sc.cam_c2w;
-        d3 origin = mk3(m[12], m[13], m[14]);
-        d3 dp = mk3(cx * m[0] + cy * m[4] + -1.0 * m[8] + m[12], cx * m[1] + cy * m[5] + -1.0 * m[9] + m[13],
-                    cx * m[2] + cy * m[6] + -1.0 * m[10] + m[14]);
-        d3 dir = normalize3(dp - origin);
-        q.o[0][at] = origin.x;
-        q.o[1][at] = origin.y;
-        q.o[2][at] = origin.z;
-        q.d[0][at] = dir.x;
-        q.d[1][at] = dir.y;
-        q.d[2][at] = dir.z;
-        q.thr[0][at] = 1.0;
-        q.thr[1][at] = 1.0;
-        q.thr[2][at] = 1.0;
-        q.slot[at] = slot;
-        q.pixel[at] = pixel;
-    }
+    uint32_t x = 0, y = 0;
+    if (!rt_shard_decode(&q.g, q.rank, slot, &x, &y)) return false;
+    pixel = y * q.g.width + x;
+    rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, 0u, RT_RNG_SITE_JITTER, 0u);
+    double sx = (((double)q.s_i + rt_rng_u0(&blk)) * q.recip_sqrt_spp) - 0.5;
+    double sy = (((double)q.s_j + rt_rng_u1(&blk)) * q.recip_sqrt_spp) - 0.5;
+    double px = (double)x + sx, py = (double)y + sy;
+    double w = (double)q.g.width, h = (double)q.g.height;
+    double aspect = w / h;
+    double ndcx = px / w, ndcy = py / h;
+    double cx = (2.0 * ndcx - 1.0) * sc.cam_fov_factor * aspect;
+    double cy = (1.0 - 2.0 * ndcy) * sc.cam_fov_factor;
+    const double *m = sc.cam_c2w;
+    origin = mk3(m[12], m[13], m[14]);
+    d3 dp = mk3(cx * m[0] + cy * m[4] + -1.0 * m[8] + m[12], cx * m[1] + cy * m[5] + -1.0 * m[9] + m[13],
+                cx * m[2] + cy * m[6] + -1.0 * m[10] + m[14]);
+    dir = normalize3(dp - origin);
+    return true;
 }
+
+// origin, direction and random-number key of queue entry i; false for a padding slot
+RT_DEV bool fetch_ray(const DevScene &sc, const RayQueue &q, const PassParams &pp, uint32_t i, d3 &o, d3 &d, uint32_t &pixel)
+{
+    if (q.primary) return primary_ray(sc, q, pp, i, o, d, pixel);
+    o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+    d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+    pixel = q.pixel[i];
+    return true;
+}
+
+RT_DEV uint32_t ray_slot(const RayQueue &q, uint32_t i) { return q.primary ? i : q.slot[i]; }
+
+#define RT_HIT_PADDING (-2) // hit.obj of a padding slot: no ray, nothing to shade
 
 // ------------------------------------------------------------------ nearest hit
 struct Candidate {
@@ -384,10 +387,11 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
         const uint32_t i = base + threadIdx.x;
         bool wants_mesh = false;
-        if (i < count) {
-            d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
-            d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
-            uint32_t pixel = q.pixel[i];
+        d3 o, d;
+        uint32_t pixel = 0u;
+        if (i < count && !fetch_ray(sc, q, pp, i, o, d, pixel)) {
+            hit.obj[i] = RT_HIT_PADDING;
+        } else if (i < count) {
             HitRec h;
             wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
             hit.t[i] = h.t;
@@ -397,7 +401,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc
             hit.uv[0][i] = h.u;
             hit.uv[1][i] = h.v;
             hit.obj[i] = h.obj;
-            if (primary_ids) primary_ids[q.slot[i]] = h.obj;
+            if (primary_ids) primary_ids[ray_slot(q, i)] = h.obj;
         }
         uint32_t at = block_append(wants_mesh, mesh_count, append_lds);
         if (wants_mesh) mesh_queue[at] = i;
@@ -442,7 +446,7 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
     hit.uv[0][i] = u;
     hit.uv[1][i] = v;
     hit.obj[i] = best_obj;
-    if (primary_ids) primary_ids[q.slot[i]] = best_obj;
+    if (primary_ids) primary_ids[ray_slot(q, i)] = best_obj;
 }
 
 // Pass 2: the rays queued by k_intersect against the mesh objects
@@ -511,7 +515,8 @@ __device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, 
 
 __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
                                                       const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
-                                                      uint32_t refill, uint32_t block_arg, uint32_t resident_waves)
+                                                      uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
+                                                      PassParams pp)
 {
     extern __shared__ double4 mesh_lds[]; // job records, (bits, rank) pairs, distance words, then the cell starts if they fit
     const uint32_t n_jobs_lds = sc.n_jobs < DEV_MESH_JOBS_LDS ? sc.n_jobs : DEV_MESH_JOBS_LDS;
@@ -594,8 +599,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
             d3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1);
             bool advance = false;
             if (!active && have_ray) {
-                wo = mk3(q.o[0][ri], q.o[1][ri], q.o[2][ri]);
-                wd = mk3(q.d[0][ri], q.d[1][ri], q.d[2][ri]);
+                uint32_t px_;
+                (void)fetch_ray(sc, q, pp, ri, wo, wd, px_);
                 // result of the walk that just ended: min_by keeps the first minimum
                 if (mtri != 0xFFFFFFFFu && (!obj_found || mt < obj_t)) {
                     obj_t = mt;
@@ -612,8 +617,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                 const uint64_t j = cursor + (uint64_t)__popcll(empty & lane_lt);
                 if (j < block_end && j < count) {
                     ri = mesh_queue[j];
-                    wo = mk3(q.o[0][ri], q.o[1][ri], q.o[2][ri]);
-                    wd = mk3(q.d[0][ri], q.d[1][ri], q.d[2][ri]);
+                    uint32_t px_;
+                    (void)fetch_ray(sc, q, pp, ri, wo, wd, px_);
                     best_obj = hit.obj[ri];
                     best_t = best_obj >= 0 ? hit.t[ri] : DBL_MAX;
                     best_aux = 0u;
@@ -727,7 +732,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                         hit.uv[0][ri] = u;
                         hit.uv[1][ri] = v;
                         hit.obj[ri] = best_obj;
-                        if (primary_ids) primary_ids[q.slot[ri]] = best_obj;
+                        if (primary_ids) primary_ids[ray_slot(q, ri)] = best_obj;
                     }
                     have_ray = false;
                 }
@@ -928,15 +933,17 @@ RT_DEV bool mesh_brute_wave(const DevScene &sc, d3 o, d3 d, int &best_obj, doubl
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
-                                                          const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids)
+                                                          const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
+                                                          PassParams pp)
 {
     const uint32_t count = *mesh_count;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t j = wave; j < count; j += n_waves) {
         const uint32_t i = mesh_queue[j];
-        d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
-        d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+        d3 o, d;
+        uint32_t px_;
+        (void)fetch_ray(sc, q, pp, i, o, d, px_);
         int best_obj = hit.obj[i];
         double best_t = best_obj >= 0 ? hit.t[i] : DBL_MAX;
         uint32_t best_aux = 0u;
@@ -1105,18 +1112,26 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc, RayQueue q
         bool alive = false;
         d3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), thr = mk3(0, 0, 0);
         uint32_t slot = 0, pixel = 0;
-        if (i < count) {
-            slot = qin.slot[i];
-            pixel = qin.pixel[i];
-            thr = mk3(qin.thr[0][i], qin.thr[1][i], qin.thr[2][i]);
-            HitRec h;
-            h.obj = hit.obj[i];
+        HitRec h;
+        h.obj = i < count ? hit.obj[i] : RT_HIT_PADDING;
+        if (h.obj != RT_HIT_PADDING) {
             h.t = 0.0;
             h.n = mk3(0, 0, 0);
             h.u = h.v = 0.0;
+            if (qin.primary) {
+                slot = i;
+                thr = mk3(1.0, 1.0, 1.0);
+                (void)primary_ray(sc, qin, pp, i, o, d, pixel);
+            } else {
+                slot = qin.slot[i];
+                pixel = qin.pixel[i];
+                thr = mk3(qin.thr[0][i], qin.thr[1][i], qin.thr[2][i]);
+                if (h.obj >= 0) {
+                    o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
+                    d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
+                }
+            }
             if (h.obj >= 0) {
-                o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
-                d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
                 h.t = hit.t[i];
                 h.n = mk3(hit.n[0][i], hit.n[1][i], hit.n[2][i]);
                 h.u = hit.uv[0][i];
@@ -1322,6 +1337,10 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         for (int k = 0; k < 2; ++k) {
             s->q[k].slot = (uint32_t *)take(4);
             s->q[k].pixel = (uint32_t *)take(4);
+            s->q[k].primary = 0;
+            s->q[k].rank = s->q[k].s_i = s->q[k].s_j = 0u;
+            s->q[k].recip_sqrt_spp = 1.0;
+            std::memset(&s->q[k].g, 0, sizeof(s->q[k].g));
         }
         s->hit.obj = (int32_t *)take(4);
         s->mesh_queue = (uint32_t *)take(4);
@@ -1497,7 +1516,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             if (blocks > 256 * 8) blocks = 256 * 8;
             if (blocks < 1) blocks = 1;
             hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), block, 0, st, s->dev, q, s->mesh_queue, mesh_count,
-                               s->hit, ids);
+                               s->hit, ids, pp);
         } else {
             // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
             // waves stay and refill their idle lanes from further blocks
@@ -1509,7 +1528,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             if (mb < 1) mb = 1;
             if (mb > max_wgs) mb = max_wgs;
             hipLaunchKernelGGL(k_mesh, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_lds_bytes, st, s->dev, q,
-                               s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES);
+                               s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp);
             walked = 1;
         }
     }
@@ -1598,10 +1617,16 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                                    n_slots, d_rgb);
             } else {
                 HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * (opts->max_depth + 2) * sizeof(uint32_t), st));
-                RT_TRACE("launching raygen grid %u", grid_for(n_slots));
+                // depth 0 reads no ray queue: entry i is slot i and its camera ray is regenerated in place
+                RayQueue q_primary = s->q[0];
+                q_primary.primary = 1;
+                q_primary.rank = rank;
+                q_primary.s_i = s_i;
+                q_primary.s_j = s_j;
+                q_primary.g = g;
+                q_primary.recip_sqrt_spp = recip;
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_counts, (int)n_slots, 1, st));
                 HIP_TRY(hipEventRecord(s->evp[0], st));
-                hipLaunchKernelGGL(k_raygen, dim3(grid_for_wide(n_slots)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, g, rank, n_slots,
-                                   s_i, s_j, recip, pp, s->q[0], s->d_counts);
                 // `live` bounds the rays of the next pass from above: exact right after a read-back,
                 // otherwise the last known value (the count never grows).  The kernels read the true
                 // count on the device; the bound only sizes grids.  Read-backs cost a stream
@@ -1620,11 +1645,12 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
                     HIP_TRY(hipEventRecord(s->evp[1 + 4 * depth], st));
-                    walked[depth] = (uint8_t)launch_intersect(s, st, live, s->q[cur], s->d_counts + depth,
+                    const RayQueue &q_in = depth == 0 ? q_primary : s->q[cur];
+                    walked[depth] = (uint8_t)launch_intersect(s, st, live, q_in, s->d_counts + depth,
                                                               s->d_counts + (opts->max_depth + 2) + depth, pp, ids,
                                                               s->evp[2 + 4 * depth]);
                     HIP_TRY(hipEventRecord(s->evp[3 + 4 * depth], st));
-                    hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, s->q[cur],
+                    hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, q_in,
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
                     HIP_TRY(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
@@ -1655,6 +1681,17 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 if (rt_debug())
                     for (uint32_t k = 0; k < passes; ++k)
                         RT_TRACE("pass %u: rays %u mesh queue %u", k, s->h_pinned[k], mesh_counts[k]);
+                {
+                    // entry 0 counted the shard's slots; its rays are the pixels inside the image
+                    uint64_t valid = 0;
+                    const uint32_t n_local = rt_shard_tiles(&g, rank);
+                    for (uint32_t lt = 0; lt < n_local; ++lt) {
+                        const uint32_t kt = lt * g.shard_count + rank, tx = kt % g.tiles_x, ty = kt / g.tiles_x;
+                        const uint32_t w = std::min(g.tile, g.width - tx * g.tile), h = std::min(g.tile, g.height - ty * g.tile);
+                        valid += (uint64_t)w * h;
+                    }
+                    s->h_pinned[0] = (uint32_t)valid;
+                }
                 local.primary_rays += s->h_pinned[0];
                 for (uint32_t k = 0; k < opts->max_depth; ++k) {
                     local.rays += s->h_pinned[k];
