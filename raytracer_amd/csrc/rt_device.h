@@ -155,6 +155,7 @@ struct DevScene {
     uint32_t n_cell_starts; // entries in cell_start
     uint32_t n_dist_words;  // words in grid_dist
     uint32_t n_jobs;
+    uint32_t n_leaves, n_meshes, n_materials, n_textures;
     uint32_t pad2;
     double background[3];
     double cam_fov_factor;

@@ -111,6 +111,48 @@ RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
 
 #define RT_BLOCK_WIDE 1024 // ray generation and shading: light on registers, heavy on queue appends
 
+// The scene's small tables (objects, leaves, meshes, materials, textures) are read by every ray
+// through chains of dependent loads: objects[k] -> leaves[leaf0] -> parameters.  From memory each
+// link costs a cache round trip of several hundred cycles - measured, the object loop of
+// k_intersect waited 27 000 cycles per 64 rays on them.  Each workgroup therefore copies the
+// tables into LDS once and the kernel works on a DevScene whose pointers lead there.  Scenes whose
+// tables exceed RT_SCENE_LDS_MAX keep reading memory.  Ends with a barrier.
+#define RT_SCENE_LDS_MAX 32768u
+static inline __host__ __device__ uint32_t scene_lds_bytes(const DevScene &sc)
+{
+    const uint32_t b = (((uint32_t)sc.n_objects * (uint32_t)sizeof(DevObject) + 15u) & ~15u) +
+                       ((sc.n_leaves * (uint32_t)sizeof(DevLeaf) + 15u) & ~15u) +
+                       ((sc.n_meshes * (uint32_t)sizeof(DevMesh) + 15u) & ~15u) +
+                       ((sc.n_materials * (uint32_t)sizeof(DevMaterial) + 15u) & ~15u) +
+                       ((sc.n_textures * (uint32_t)sizeof(DevTexture) + 15u) & ~15u);
+    return b <= RT_SCENE_LDS_MAX ? b : 0u;
+}
+
+RT_DEV DevScene scene_in_lds(const DevScene &sc, unsigned char *lds)
+{
+    DevScene v = sc;
+    if (scene_lds_bytes(sc) != 0u) {
+        unsigned char *p = lds;
+#define RT_STAGE(FIELD, TYPE, COUNT)                                                                                   \
+    do {                                                                                                               \
+        const uint32_t words_ = (uint32_t)(COUNT) * (uint32_t)(sizeof(TYPE) / 4);                                      \
+        const uint32_t *src_ = reinterpret_cast<const uint32_t *>(sc.FIELD);                                           \
+        uint32_t *dst_ = reinterpret_cast<uint32_t *>(p);                                                              \
+        for (uint32_t i_ = threadIdx.x; i_ < words_; i_ += blockDim.x) dst_[i_] = src_[i_];                            \
+        v.FIELD = reinterpret_cast<const TYPE *>(p);                                                                   \
+        p += (words_ * 4u + 15u) & ~15u;                                                                               \
+    } while (0)
+        RT_STAGE(objects, DevObject, sc.n_objects);
+        RT_STAGE(leaves, DevLeaf, sc.n_leaves);
+        RT_STAGE(meshes, DevMesh, sc.n_meshes);
+        RT_STAGE(materials, DevMaterial, sc.n_materials);
+        RT_STAGE(textures, DevTexture, sc.n_textures);
+#undef RT_STAGE
+    }
+    __syncthreads();
+    return v;
+}
+
 // ------------------------------------------------------------------ ray generation
 // get_stratified_ray + Camera::pixel_ray (system.rs:237-242, 57-66) for slot `slot` of the shard;
 // false for the padding slots beyond the image edge
@@ -374,10 +416,12 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 }
 
 template <bool CSG, bool MEDIUM, bool TORUS>
-__global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
+__global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          uint32_t *mesh_queue, uint32_t *mesh_count)
 {
+    extern __shared__ double4 scene_lds[];
+    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     __shared__ uint32_t append_lds[RT_BLOCK / 64 + 1];
     const uint32_t count = *count_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -1100,9 +1144,11 @@ RT_DEV bool shade_one(const DevScene &sc, d3 &o, d3 &d, d3 &thr, uint32_t pixel,
     return pp.depth + 1u < pp.max_depth;
 }
 
-__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
+__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
                                                      RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
 {
+    extern __shared__ double4 scene_lds[];
+    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
     const uint32_t count = *count_in_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -1169,9 +1215,11 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc, RayQueue q
 // The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
 template <bool CSG, bool MEDIUM, bool TORUS>
-__global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
+__global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh)
 {
+    extern __shared__ double4 scene_lds[];
+    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     const uint32_t count = counts[pp.depth];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -1420,6 +1468,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     if ((rc = upload(s, flat.textures, &s->dev.textures))) return fail(rc);
     if ((rc = upload(s, flat.image_data, &s->dev.image_data))) return fail(rc);
     s->dev.n_objects = (int32_t)flat.objects.size();
+    s->dev.n_leaves = (uint32_t)flat.leaves.size();
+    s->dev.n_meshes = (uint32_t)flat.meshes.size();
+    s->dev.n_materials = (uint32_t)flat.materials.size();
+    s->dev.n_textures = (uint32_t)flat.textures.size();
     for (const DevObject &ob : flat.objects) {
         if (ob.kind == DO_CSG || (ob.kind == DO_MEDIUM && ob.prog_len > 0)) s->has_csg = true;
         if (ob.kind == DO_MEDIUM) s->has_medium = true;
@@ -1493,7 +1545,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
 {
     dim3 grid(grid_for(live)), block(RT_BLOCK);
 #define LAUNCH_I(C, M, T)                                                                                              \
-    hipLaunchKernelGGL((k_intersect<C, M, T>), grid, block, 0, st, s->dev, q, count_ptr, s->hit, pp, ids, s->d_guards, \
+    hipLaunchKernelGGL((k_intersect<C, M, T>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, s->hit, pp, ids, s->d_guards, \
                        s->mesh_queue, mesh_count)
     const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
     switch (variant) {
@@ -1543,7 +1595,7 @@ static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQue
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
 #define LAUNCH_T(C, M, T)                                                                                              \
-    hipLaunchKernelGGL((k_tail<C, M, T>), dim3((uint32_t)blocks), dim3(RT_BLOCK), 0, st, s->dev, q, s->d_counts,       \
+    hipLaunchKernelGGL((k_tail<C, M, T>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, s->d_counts,       \
                        s->d_counts, d_rgb, pp, s->d_guards, s->has_mesh ? 1 : 0)
     const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
     switch (variant) {
@@ -1650,7 +1702,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                                                               s->d_counts + (opts->max_depth + 2) + depth, pp, ids,
                                                               s->evp[2 + 4 * depth]);
                     HIP_TRY(hipEventRecord(s->evp[3 + 4 * depth], st));
-                    hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, q_in,
+                    hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st, s->dev, q_in,
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
                     HIP_TRY(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
