@@ -72,6 +72,20 @@ def test_several_meshes_and_mesh_objects(rt):
     _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
 
 
+def test_stats_account_for_every_stage(rt):
+    """rt_stats: per-kernel times from HIP events, ray and mesh-queue counts; the tail kernel's rays are counted."""
+    o = rt.Options(width=256, height=192, samples=1, seed=4)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert st.rays == rst.rays and st.primary_rays == 256 * 192
+    assert st.bounce_passes >= 3 and st.n_intersect_launches >= 1
+    assert 0 < st.intersect_rays <= st.rays            # rays the tail kernel traced are in rays only
+    assert st.mesh_rays <= st.intersect_rays
+    assert st.ms_intersect > 0 and st.ms_shade > 0 and st.ms_mesh > 0 and st.ms_tail > 0
+    assert st.ms_device >= st.ms_intersect + st.ms_mesh + st.ms_shade + st.ms_tail - 1e-3
+
+
 def test_plumbing_config_three_spheres_640x480(rt):
     """BASELINE configs[0]: three-spheres at 640x480, samples=1, seed 1."""
     o = rt.Options(width=640, height=480, samples=1, seed=1)
