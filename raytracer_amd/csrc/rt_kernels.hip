@@ -1339,6 +1339,7 @@ struct rt_scene {
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evp; // per-pass timing events: [0] before raygen, then 4 per depth
+    std::vector<hipEvent_t> evr; // per depth: its queue length has been copied back
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -1400,7 +1401,7 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         HIP_TRY(hipMalloc((void **)&s->d_counts, 2 * (max_depth + 2) * sizeof(uint32_t)));
         if (s->h_pinned) (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
-        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (2 * (max_depth + 2) + 8) * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (3 * (max_depth + 2) + 8) * sizeof(uint32_t), hipHostMallocDefault));
         s->counts_cap = max_depth + 2;
     }
     if (!s->d_guards) HIP_TRY(hipMalloc((void **)&s->d_guards, 8 * sizeof(uint32_t)));
@@ -1408,6 +1409,11 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         s->evp.push_back(e);
+    }
+    while (s->evr.size() < (size_t)max_depth + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->evr.push_back(e);
     }
     if (!s->ev0) {
         HIP_TRY(hipEventCreate(&s->ev0));
@@ -1499,6 +1505,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->evp) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->evr) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -1679,16 +1686,16 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 q_primary.recip_sqrt_spp = recip;
                 HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_counts, (int)n_slots, 1, st));
                 HIP_TRY(hipEventRecord(s->evp[0], st));
-                // `live` bounds the rays of the next pass from above: exact right after a read-back,
-                // otherwise the last known value (the count never grows).  The kernels read the true
-                // count on the device; the bound only sizes grids.  Read-backs cost a stream
-                // synchronisation, so after the first bounces they come every fourth pass.
+                // `live` bounds the rays of the next pass from above: the newest count that has come
+                // back (counts never grow).  The kernels read the true count on the device; the bound
+                // only sizes grids and picks between k_mesh and k_mesh_brute.
                 uint32_t live = n_slots;
                 // paths left at which the tail kernel takes over (one wave per path, meshes by brute force)
                 static const uint32_t tail_env = getenv("RT_TAIL_MAX") ? (uint32_t)atoi(getenv("RT_TAIL_MAX")) : 0xFFFFFFFFu;
                 uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 8192u;
                 if (tail_max > 8192u) tail_max = 8192u;
                 if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
+                static const uint32_t run_ahead = getenv("RT_RUN_AHEAD") ? (uint32_t)atoi(getenv("RT_RUN_AHEAD")) : 2u;
                 int cur = 0;
                 uint32_t passes = 0;
                 int tail_at = -1; // depth at which k_tail took over
@@ -1707,22 +1714,32 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     HIP_TRY(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;
-                    if (depth < 3 || (depth & 3u) == 3u || depth + 1 == opts->max_depth || live <= 8u * tail_max) {
-                        HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts + depth + 1, sizeof(uint32_t),
-                                               hipMemcpyDeviceToHost, st));
-                        HIP_TRY(hipStreamSynchronize(st));
-                        live = s->h_pinned[0];
-                        RT_TRACE("depth %u live %u", depth, live);
-                        if (live == 0) break;
-                        if (live <= tail_max && depth + 1 < opts->max_depth) {
-                            // few paths left: one launch takes them all to their ends
-                            pp.depth = depth + 1;
-                            HIP_TRY(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
-                            launch_tail(s, st, live, s->q[cur], pp, d_rgb);
-                            HIP_TRY(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
-                            tail_at = (int)depth + 1;
+                    // queue length of the next pass: copied back asynchronously after every pass.  The
+                    // host waits for the copy of two passes ago only, so the device always has work
+                    // queued across the copy's round trip; near the tail threshold (and on the last
+                    // pass) it waits for the newest copy, because the switch needs the count.
+                    uint32_t *h_live = s->h_pinned + 2 * (opts->max_depth + 2) + 8;
+                    HIP_TRY(hipMemcpyAsync(h_live + depth + 1, s->d_counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipEventRecord(s->evr[depth + 1], st));
+                    const bool exact = live <= 8u * tail_max || depth + 1 == opts->max_depth || run_ahead == 0u;
+                    int known = exact ? (int)depth + 1 : (int)depth + 1 - (int)run_ahead;
+                    if (known >= 1) HIP_TRY(hipEventSynchronize(s->evr[known]));
+                    for (int k = (int)depth + 1; k > known && k >= 1; --k)
+                        if (hipEventQuery(s->evr[k]) == hipSuccess) {
+                            known = k;
                             break;
                         }
+                    if (known >= 1 && h_live[known] < live) live = h_live[known];
+                    RT_TRACE("depth %u: count of depth %d known, bound %u", depth, known, live);
+                    if (live == 0) break;
+                    if (live <= tail_max && depth + 1 < opts->max_depth) {
+                        // few paths left: one launch takes them all to their ends
+                        pp.depth = depth + 1;
+                        HIP_TRY(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
+                        launch_tail(s, st, live, s->q[cur], pp, d_rgb);
+                        HIP_TRY(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
+                        tail_at = (int)depth + 1;
+                        break;
                     }
                 }
                 HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, 2 * (opts->max_depth + 2) * sizeof(uint32_t),
