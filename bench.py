@@ -106,7 +106,7 @@ def main():
 
     n_slots = [system.shard_pixels(opts, r, world) for r in range(world)]
     max_slots = max(n_slots)
-    shard = torch.zeros(max_slots * 3, dtype=torch.float64, device=dev)
+    shard = torch.zeros(max_slots * 3, dtype=torch.float64, device=dev) if world > 1 else None
     full = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if rank == 0 else None
     gathered = [torch.zeros(max_slots * 3, dtype=torch.float64, device=dev) for _ in range(world)] \
         if (rank == 0 and world > 1) else None
@@ -114,14 +114,15 @@ def main():
 
     def step(k):
         opts.seed = 1 + k
-        st = dscene.render_shard(opts, rank, world, shard.data_ptr(), None, stream)
         if world > 1:
+            st = dscene.render_shard(opts, rank, world, shard.data_ptr(), None, stream)
             dist.gather(shard, gathered, dst=0)
             if rank == 0:
                 for r in range(world):
                     system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=stream)
         else:
-            system.unshard(opts, 0, 1, shard.data_ptr(), full.data_ptr(), stream=stream)
+            # a single GPU writes the row-major image directly (RT_FLAG_ROW_MAJOR): nothing to reassemble
+            st = dscene.render_shard(opts, 0, 1, full.data_ptr(), None, stream, row_major=True)
         return st
 
     def barrier():

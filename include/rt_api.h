@@ -170,8 +170,12 @@ typedef struct rt_options {
     uint32_t tile_size;   /* multiple of 8; 0 -> 64 */
     uint32_t shard_rank;  /* 0 .. shard_count-1 */
     uint32_t shard_count; /* 0 -> 1 */
-    uint32_t flags;       /* reserved, 0 */
+    uint32_t flags;       /* RT_FLAG_* */
 } rt_options;
+
+/* rt_options.flags */
+#define RT_FLAG_ROW_MAJOR 1u /* shard_count == 1 only: outputs are indexed y * width + x instead of by shard
+                             * slot (width * height elements), so a whole image needs no rt_unshard_device */
 
 typedef struct rt_stats {
     uint64_t rays;         /* Ray::trace invocations, primary + secondary  */

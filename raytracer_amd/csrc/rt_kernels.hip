@@ -47,6 +47,7 @@ struct RayQueue {
     // pixel's camera ray, regenerated wherever it is needed (a jitter draw and a normalise) instead
     // of being written by one kernel and read back by three: 1.8 GB less traffic per 4K frame.
     int primary;
+    int row_major; // outputs are indexed by pixel instead of by shard slot (RT_FLAG_ROW_MAJOR)
     uint32_t rank, s_i, s_j;
     rt_shard_geom g;
     double recip_sqrt_spp;
@@ -189,7 +190,15 @@ RT_DEV bool fetch_ray(const DevScene &sc, const RayQueue &q, const PassParams &p
     return true;
 }
 
-RT_DEV uint32_t ray_slot(const RayQueue &q, uint32_t i) { return q.primary ? i : q.slot[i]; }
+// index of the ray's pixel in the output buffers
+RT_DEV uint32_t ray_slot(const RayQueue &q, uint32_t i)
+{
+    if (!q.primary) return q.slot[i];
+    if (!q.row_major) return i;
+    uint32_t x = 0, y = 0;
+    (void)rt_shard_decode(&q.g, q.rank, i, &x, &y);
+    return y * q.g.width + x;
+}
 
 #define RT_HIT_PADDING (-2) // hit.obj of a padding slot: no ray, nothing to shade
 
@@ -1165,9 +1174,9 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
             h.n = mk3(0, 0, 0);
             h.u = h.v = 0.0;
             if (qin.primary) {
-                slot = i;
                 thr = mk3(1.0, 1.0, 1.0);
                 (void)primary_ray(sc, qin, pp, i, o, d, pixel);
+                slot = qin.row_major ? pixel : i;
             } else {
                 slot = qin.slot[i];
                 pixel = qin.pixel[i];
@@ -1269,11 +1278,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, 
 }
 
 // max_depth == 0: every primary ray returns the background (system.rs:113-114)
-__global__ void k_fill_background(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots, double *fb)
+__global__ void k_fill_background(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots, double *fb, int row_major)
 {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t x, y;
     if (slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y)) {
+        if (row_major) slot = y * g.width + x;
         fb[(size_t)slot * 3 + 0] += sc.background[0];
         fb[(size_t)slot * 3 + 1] += sc.background[1];
         fb[(size_t)slot * 3 + 2] += sc.background[2];
@@ -1387,6 +1397,7 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
             s->q[k].slot = (uint32_t *)take(4);
             s->q[k].pixel = (uint32_t *)take(4);
             s->q[k].primary = 0;
+            s->q[k].row_major = 0;
             s->q[k].rank = s->q[k].s_i = s->q[k].s_j = 0u;
             s->q[k].recip_sqrt_spp = 1.0;
             std::memset(&s->q[k].g, 0, sizeof(s->q[k].g));
@@ -1536,6 +1547,10 @@ static int check_options(const rt_options *o)
         rt_host::set_last_error("rt_options: shard_rank out of range");
         return RT_ERR_INVALID;
     }
+    if ((o->flags & RT_FLAG_ROW_MAJOR) && sc > 1u) {
+        rt_host::set_last_error("rt_options: RT_FLAG_ROW_MAJOR needs shard_count 1");
+        return RT_ERR_INVALID;
+    }
     if ((uint64_t)o->width * o->height > 0xFFFFFFFFull || o->max_depth > 0xFFFFu) {
         rt_host::set_last_error("rt_options: image or depth too large for the random-number key");
         return RT_ERR_INVALID;
@@ -1656,8 +1671,10 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
     RT_TRACE("ev0 %p st %p d_rgb %p", (void *)s->ev0, (void *)st, (void *)d_rgb);
     HIP_TRY(hipEventRecord(s->ev0, st));
     RT_TRACE("event recorded");
-    HIP_TRY(hipMemsetAsync(d_rgb, 0, (size_t)n_slots * 3 * sizeof(double), st)); // alloc_render_buf
-    if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)n_slots * sizeof(int32_t), st));
+    const bool row_major = (opts->flags & RT_FLAG_ROW_MAJOR) != 0u; // check_options: only with a single shard
+    const size_t n_out = row_major ? (size_t)opts->width * opts->height : (size_t)n_slots;
+    HIP_TRY(hipMemsetAsync(d_rgb, 0, n_out * 3 * sizeof(double), st)); // alloc_render_buf
+    if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xFF, n_out * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_guards, 0, 8 * sizeof(uint32_t), st));
     RT_TRACE("memsets queued");
 
@@ -1673,12 +1690,13 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
             pp.bias = opts->bias;
             if (opts->max_depth == 0) {
                 hipLaunchKernelGGL(k_fill_background, dim3((n_slots + 255) / 256), dim3(256), 0, st, s->dev, g, rank,
-                                   n_slots, d_rgb);
+                                   n_slots, d_rgb, row_major ? 1 : 0);
             } else {
                 HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * (opts->max_depth + 2) * sizeof(uint32_t), st));
                 // depth 0 reads no ray queue: entry i is slot i and its camera ray is regenerated in place
                 RayQueue q_primary = s->q[0];
                 q_primary.primary = 1;
+                q_primary.row_major = row_major ? 1 : 0;
                 q_primary.rank = rank;
                 q_primary.s_i = s_i;
                 q_primary.s_j = s_j;
@@ -1853,7 +1871,7 @@ extern "C" int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, co
 
 struct HostRenderCtx {
     const rt_options *opts;
-    double *d_shard_rgb, *d_full_rgb;
+    double *d_full_rgb; // row-major running sum on the device
     double *h_rgb;
     rt_progress_cb cb;
     void *user;
@@ -1863,8 +1881,6 @@ static int host_render_stratum(void *u, uint32_t done, uint32_t total)
 {
     HostRenderCtx *c = (HostRenderCtx *)u;
     if (!c->cb) return 0;
-    int rc = rt_unshard_device(c->opts, 0, c->d_shard_rgb, c->d_full_rgb, nullptr, nullptr, nullptr);
-    if (rc) return rc;
     size_t n = (size_t)c->opts->width * c->opts->height;
     if (hipMemcpy(c->h_rgb, c->d_full_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
         rt_host::set_last_error("rt_render: copy to host failed");
@@ -1886,14 +1902,12 @@ extern "C" int rt_render(rt_scene *scene, const rt_options *opts_in, double *rgb
     opts.shard_rank = 0;
     opts.shard_count = 1;
     HIP_TRY(hipSetDevice(scene->device));
+    opts.flags |= RT_FLAG_ROW_MAJOR; // the kernels write y * width + x directly
     const size_t n = (size_t)opts.width * opts.height;
-    const size_t n_slots = rt_shard_pixels(&opts);
-    double *d_shard = nullptr, *d_full = nullptr;
-    int32_t *d_ids_shard = nullptr, *d_ids_full = nullptr;
+    double *d_full = nullptr;
+    int32_t *d_ids_full = nullptr;
     auto cleanup = [&]() {
-        if (d_shard) (void)hipFree(d_shard);
         if (d_full) (void)hipFree(d_full);
-        if (d_ids_shard) (void)hipFree(d_ids_shard);
         if (d_ids_full) (void)hipFree(d_ids_full);
     };
 #define TRY_OR_CLEAN(expr)                                                                                             \
@@ -1905,15 +1919,10 @@ extern "C" int rt_render(rt_scene *scene, const rt_options *opts_in, double *rgb
             return RT_ERR_DEVICE;                                                                                      \
         }                                                                                                              \
     } while (0)
-    TRY_OR_CLEAN(hipMalloc((void **)&d_shard, n_slots * 3 * sizeof(double)));
     TRY_OR_CLEAN(hipMalloc((void **)&d_full, n * 3 * sizeof(double)));
-    if (primary_ids) {
-        TRY_OR_CLEAN(hipMalloc((void **)&d_ids_shard, n_slots * sizeof(int32_t)));
-        TRY_OR_CLEAN(hipMalloc((void **)&d_ids_full, n * sizeof(int32_t)));
-    }
-    HostRenderCtx ctx{&opts, d_shard, d_full, rgb_sum, cb, user};
-    rc = render_strata(scene, &opts, d_shard, d_ids_shard, stats, nullptr, host_render_stratum, &ctx);
-    if (rc == RT_OK) rc = rt_unshard_device(&opts, 0, d_shard, d_full, d_ids_shard, d_ids_full, nullptr);
+    if (primary_ids) TRY_OR_CLEAN(hipMalloc((void **)&d_ids_full, n * sizeof(int32_t)));
+    HostRenderCtx ctx{&opts, d_full, rgb_sum, cb, user};
+    rc = render_strata(scene, &opts, d_full, d_ids_full, stats, nullptr, host_render_stratum, &ctx);
     if (rc == RT_OK) {
         TRY_OR_CLEAN(hipMemcpy(rgb_sum, d_full, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
         if (primary_ids) TRY_OR_CLEAN(hipMemcpy(primary_ids, d_ids_full, n * sizeof(int32_t), hipMemcpyDeviceToHost));

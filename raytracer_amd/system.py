@@ -22,10 +22,13 @@ class Options:
     seed: int = 1
     tile_size: int = 64
 
-    def to_c(self, shard_rank=0, shard_count=1):
+    def to_c(self, shard_rank=0, shard_count=1, flags=0):
         return _capi.rt_options(width=self.width, height=self.height, samples=self.samples, max_depth=self.max_depth,
                                 bias=self.bias, seed=self.seed, tile_size=self.tile_size, shard_rank=shard_rank,
-                                shard_count=shard_count, flags=0)
+                                shard_count=shard_count, flags=flags)
+
+
+ROW_MAJOR = 1  # RT_FLAG_ROW_MAJOR
 
 
 class RenderProgress:
@@ -91,9 +94,10 @@ class DeviceScene:
             progress.render_finished(options, rgb)
         return rgb, ids, stats
 
-    def render_shard(self, options, shard_rank, shard_count, d_rgb_ptr, d_ids_ptr=None, stream=None):
-        """One shard of the tiles into caller-owned device buffers (rt_render_device)."""
-        o = options.to_c(shard_rank, shard_count)
+    def render_shard(self, options, shard_rank, shard_count, d_rgb_ptr, d_ids_ptr=None, stream=None, row_major=False):
+        """One shard of the tiles into caller-owned device buffers (rt_render_device).  `row_major`
+        (a single shard only): the buffers are width * height elements indexed y * width + x."""
+        o = options.to_c(shard_rank, shard_count, ROW_MAJOR if row_major else 0)
         stats = _capi.rt_stats()
         rc = self._lib.rt_render_device(self._h, C.byref(o), C.c_void_p(d_rgb_ptr),
                                         C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(stats),

@@ -72,6 +72,31 @@ def test_several_meshes_and_mesh_objects(rt):
     _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
 
 
+def test_row_major_output_equals_unsharded(rt):
+    """RT_FLAG_ROW_MAJOR (one shard): the kernels index the outputs by pixel; same image as shard
+    layout + unshard, bit for bit, also when the image does not fill its last tiles."""
+    import torch
+    from raytracer_amd import system
+    o = rt.Options(width=300, height=170, samples=4, seed=21)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    dev = rt.DeviceScene(sc)
+    whole, wids, wst = dev.render(o)                     # rt_render: row-major internally
+    n = system.shard_pixels(o, 0, 1)
+    assert n > 300 * 170                                 # padding slots exist
+    buf = torch.zeros(n * 3, dtype=torch.float64, device="cuda")
+    ibuf = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = dev.render_shard(o, 0, 1, buf.data_ptr(), ibuf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    full = torch.zeros(170 * 300 * 3, dtype=torch.float64, device="cuda")
+    fids = torch.zeros(170 * 300, dtype=torch.int32, device="cuda")
+    system.unshard(o, 0, 1, buf.data_ptr(), full.data_ptr(), ibuf.data_ptr(), fids.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy().reshape(170, 300, 3), whole)
+    assert np.array_equal(fids.cpu().numpy().reshape(170, 300), wids)
+    assert st.rays == wst.rays
+    with pytest.raises(RuntimeError):                    # the flag is for a single shard
+        dev.render_shard(o, 0, 2, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream, row_major=True)
+
+
 def test_stats_account_for_every_stage(rt):
     """rt_stats: per-kernel times from HIP events, ray and mesh-queue counts; the tail kernel's rays are counted."""
     o = rt.Options(width=256, height=192, samples=1, seed=4)
