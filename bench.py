@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo (with --same-device) rehearses the multi-rank path on a one-GPU box: shards are gathered through host memory")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -94,10 +97,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     opts = rt.Options(width=args.width, height=args.height, samples=args.samples, seed=1)
     scene = rt.parse_file(opts, os.path.join(ROOT, "tests", "assets", "scenes", args.scene + ".scene"),
@@ -116,7 +124,15 @@ def main():
         opts.seed = 1 + k
         if world > 1:
             st = dscene.render_shard(opts, rank, world, shard.data_ptr(), None, stream)
-            dist.gather(shard, gathered, dst=0)
+            if args.backend == "nccl":
+                dist.gather(shard, gathered, dst=0)
+            else:
+                host = shard.cpu()
+                parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[r].copy_(parts[r])
             if rank == 0:
                 for r in range(world):
                     system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=stream)
@@ -126,6 +142,7 @@ def main():
         return st
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -153,7 +170,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
