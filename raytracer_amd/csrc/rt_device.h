@@ -100,6 +100,8 @@ struct DevMesh {
     double qmin[3], qmax[3]; // Mesh::new bounds, which include the origin (mesh.rs:32-42)
     double bmin[3], bmax[3]; // grid bounds: the tight bounds of the triangles, padded
     double cell[3], inv_cell[3];
+    // groups of up to 64 neighbouring triangles for the wave-per-ray kernels (k_mesh_brute, k_tail)
+    uint32_t grp0, n_groups;
 };
 
 // One (mesh object, mesh) pair, in the order Ray::trace / Composite::intersect would visit them:
@@ -145,6 +147,9 @@ struct DevScene {
     const double *cell_tris; // 10 per (cell, triangle) reference, in cell order: the 9 above + the triangle index (low word)
     const uint32_t *tri_n; // 3 per triangle (normal indices, mesh-relative)
     const double *tri_nrm; // 9 per triangle: its three vertex normals
+    const double *grp_box;   // 6 per group: padded bounds (min xyz, max xyz)
+    const double *grp_tris;  // 64 slots per group x 9: the triangle records in group order
+    const uint32_t *grp_idx; // 64 slots per group: the triangle's index in its mesh, ~0u for an empty slot
     const DevMeshJob *jobs;
     const double *normals; // xyz
     const DevMaterial *materials;

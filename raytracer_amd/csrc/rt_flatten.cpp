@@ -460,6 +460,48 @@ struct Flattener {
         }
         out.cell_start.push_back((uint32_t)(out.cell_tris.size() / 10));
         if (out.grid_bits.size() / 2 > DEV_GRID_MAX_WORDS) throw Err{RT_ERR_UNSUPPORTED, "mesh grids exceed the device budget"};
+        // Groups of 64 triangles that lie together (Morton order of the centroids) with their padded
+        // bounds: a wave that tests one ray against a whole mesh (k_mesh_brute, k_tail) first tests
+        // the group boxes, one per lane, and then only the groups whose box the ray meets.
+        {
+            std::vector<std::pair<uint64_t, uint32_t>> order(m.n_triangles);
+            for (uint32_t t = 0; t < m.n_triangles; ++t) {
+                uint64_t code = 0;
+                uint32_t qc[3];
+                for (int k = 0; k < 3; ++k) {
+                    const double c = (pb[t].lo[k] + pb[t].hi[k]) * 0.5;
+                    double f = (c - dm.bmin[k]) / (dm.bmax[k] - dm.bmin[k]);
+                    f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+                    qc[k] = (uint32_t)(f * 1023.0);
+                }
+                for (int b = 9; b >= 0; --b)
+                    for (int k = 0; k < 3; ++k) code = (code << 1) | ((qc[k] >> b) & 1u);
+                order[t] = {code, t};
+            }
+            std::sort(order.begin(), order.end());
+            dm.grp0 = (uint32_t)(out.grp_idx.size() / 64);
+            dm.n_groups = (m.n_triangles + 63u) / 64u;
+            for (uint32_t g = 0; g < dm.n_groups; ++g) {
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (uint32_t sl = 0; sl < 64u; ++sl) {
+                    const uint32_t at = g * 64u + sl;
+                    if (at < m.n_triangles) {
+                        const uint32_t t = order[at].second;
+                        out.grp_idx.push_back(t);
+                        for (int k = 0; k < 9; ++k) out.grp_tris.push_back(out.tris[((size_t)dm.tri0 + t) * 9 + k]);
+                        for (int k = 0; k < 3; ++k) {
+                            lo[k] = std::fmin(lo[k], pb[t].lo[k]);
+                            hi[k] = std::fmax(hi[k], pb[t].hi[k]);
+                        }
+                    } else {
+                        out.grp_idx.push_back(0xFFFFFFFFu);
+                        for (int k = 0; k < 9; ++k) out.grp_tris.push_back(0.0);
+                    }
+                }
+                for (int k = 0; k < 3; ++k) out.grp_box.push_back(lo[k] - 2.0 * pad);
+                for (int k = 0; k < 3; ++k) out.grp_box.push_back(hi[k] + 2.0 * pad);
+            }
+        }
         out.meshes.push_back(dm);
         ++obj.n_meshes;
     }

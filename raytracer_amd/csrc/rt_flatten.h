@@ -21,6 +21,8 @@ struct FlatScene {
     std::vector<uint32_t> tri_n;
     std::vector<double> tri_nrm;
     std::vector<DevMeshJob> jobs;
+    std::vector<double> grp_box, grp_tris;
+    std::vector<uint32_t> grp_idx;
     std::vector<double> normals;
     std::vector<DevMaterial> materials;
     std::vector<DevTexture> textures;

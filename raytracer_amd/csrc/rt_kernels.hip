@@ -937,32 +937,46 @@ RT_DEV bool mesh_brute_wave(const DevScene &sc, d3 o, d3 d, int &best_obj, doubl
         for (int mi = 0; mi < ob.n_meshes; ++mi) {
             const DevMesh &m = sc.meshes[ob.mesh0 + mi];
             if (!mesh_box_hit(m, ry.o, inv)) continue;
-            const double *__restrict__ tris = sc.tris + (size_t)m.tri0 * 9;
             double lt = 1.0e300;
             uint32_t ltri = 0xFFFFFFFFu;
-            // three records per step, loaded before the first test: the loop is bound by the
-            // latency of its loads, and this way three are in flight at a time
-            for (uint32_t base = lane; base < m.n_tris; base += 192u) {
-                const uint32_t i0 = base, i1 = base + 64u, i2 = base + 128u;
-                const uint32_t j1 = i1 < m.n_tris ? i1 : i0, j2 = i2 < m.n_tris ? i2 : i0; // out of range: repeat i0
-                const double *a = tris + (size_t)i0 * 9, *b = tris + (size_t)j1 * 9, *c = tris + (size_t)j2 * 9;
-                const d3 a0 = mk3(a[0], a[1], a[2]), a1 = mk3(a[3], a[4], a[5]), a2 = mk3(a[6], a[7], a[8]);
-                const d3 b0 = mk3(b[0], b[1], b[2]), b1 = mk3(b[3], b[4], b[5]), b2 = mk3(b[6], b[7], b[8]);
-                const d3 c0 = mk3(c[0], c[1], c[2]), c1 = mk3(c[3], c[4], c[5]), c2 = mk3(c[6], c[7], c[8]);
-                double t, u, v;
-                // indices grow within a lane, and a repeated i0 cannot beat itself (t < lt is strict):
-                // the first of equal t's is the lowest index
-                if (tri_hit_v(a0, a1, a2, ry.o, ry.d, t, u, v) && t < lt) {
-                    lt = t;
-                    ltri = i0;
+            // group boxes first, one per lane; then the triangles of the groups the ray meets, one per lane
+            for (uint32_t g0 = 0; g0 < m.n_groups; g0 += 64u) {
+                bool meets = false;
+                if (g0 + lane < m.n_groups) {
+                    const double *bx = sc.grp_box + (size_t)(m.grp0 + g0 + lane) * 6;
+                    double t0 = 0.0, t1 = 1.0e300; // NaNs (0 * inf) drop out of fmin / fmax: the box then counts as met
+                    const double ax = (bx[0] - ry.o.x) * inv.x, bxx = (bx[3] - ry.o.x) * inv.x;
+                    t0 = fmax(t0, fmin(ax, bxx));
+                    t1 = fmin(t1, fmax(ax, bxx));
+                    const double ay = (bx[1] - ry.o.y) * inv.y, by = (bx[4] - ry.o.y) * inv.y;
+                    t0 = fmax(t0, fmin(ay, by));
+                    t1 = fmin(t1, fmax(ay, by));
+                    const double az = (bx[2] - ry.o.z) * inv.z, bz = (bx[5] - ry.o.z) * inv.z;
+                    t0 = fmax(t0, fmin(az, bz));
+                    t1 = fmin(t1, fmax(az, bz));
+                    meets = !(t0 > t1 + 1e-9 * (fabs(t1) + 1.0));
                 }
-                if (tri_hit_v(b0, b1, b2, ry.o, ry.d, t, u, v) && t < lt) {
-                    lt = t;
-                    ltri = j1;
-                }
-                if (tri_hit_v(c0, c1, c2, ry.o, ry.d, t, u, v) && t < lt) {
-                    lt = t;
-                    ltri = j2;
+                unsigned long long mask = __ballot(meets);
+                while (mask) {
+                    // two groups per step, loaded before the first test
+                    const uint32_t ga = g0 + (uint32_t)__ffsll((long long)mask) - 1u;
+                    mask &= mask - 1ull;
+                    const uint32_t gb = mask ? g0 + (uint32_t)__ffsll((long long)mask) - 1u : ga;
+                    mask &= mask - 1ull;
+                    const size_t sa = (size_t)(m.grp0 + ga) * 64u + lane, sb = (size_t)(m.grp0 + gb) * 64u + lane;
+                    const uint32_t ia = sc.grp_idx[sa], ib = gb != ga ? sc.grp_idx[sb] : 0xFFFFFFFFu;
+                    const double *a = sc.grp_tris + sa * 9, *b = sc.grp_tris + sb * 9;
+                    const d3 a0 = mk3(a[0], a[1], a[2]), a1 = mk3(a[3], a[4], a[5]), a2 = mk3(a[6], a[7], a[8]);
+                    const d3 b0 = mk3(b[0], b[1], b[2]), b1 = mk3(b[3], b[4], b[5]), b2 = mk3(b[6], b[7], b[8]);
+                    double t, u, v;
+                    if (ia != 0xFFFFFFFFu && tri_hit_v(a0, a1, a2, ry.o, ry.d, t, u, v) && (t < lt || (t == lt && ia < ltri))) {
+                        lt = t;
+                        ltri = ia;
+                    }
+                    if (ib != 0xFFFFFFFFu && tri_hit_v(b0, b1, b2, ry.o, ry.d, t, u, v) && (t < lt || (t == lt && ib < ltri))) {
+                        lt = t;
+                        ltri = ib;
+                    }
                 }
             }
             wave_min_hit(lt, ltri);
@@ -1470,6 +1484,9 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     s->dev.n_grid_words = (uint32_t)(flat.grid_bits.size() / 2);
     if ((rc = upload(s, flat.grid_dist, &s->dev.grid_dist))) return fail(rc);
     if ((rc = upload(s, flat.tri_nrm, &s->dev.tri_nrm))) return fail(rc);
+    if ((rc = upload(s, flat.grp_box, &s->dev.grp_box))) return fail(rc);
+    if ((rc = upload(s, flat.grp_tris, &s->dev.grp_tris))) return fail(rc);
+    if ((rc = upload(s, flat.grp_idx, &s->dev.grp_idx))) return fail(rc);
     if ((rc = upload(s, flat.jobs, &s->dev.jobs))) return fail(rc);
     s->dev.n_cell_starts = (uint32_t)flat.cell_start.size();
     s->dev.n_dist_words = (uint32_t)flat.grid_dist.size();
@@ -1609,7 +1626,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
     return walked;
 }
 
-#define RT_TAIL_MAX_TESTS 12000000ull // paths x triangles below which k_tail takes the rest of the stratum (measured)
+#define RT_TAIL_MAX_TESTS 36000000ull // paths x triangles below which k_tail takes the rest of the stratum (measured)
 
 static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const PassParams &pp, double *d_rgb)
 {
@@ -1710,8 +1727,8 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 uint32_t live = n_slots;
                 // paths left at which the tail kernel takes over (one wave per path, meshes by brute force)
                 static const uint32_t tail_env = getenv("RT_TAIL_MAX") ? (uint32_t)atoi(getenv("RT_TAIL_MAX")) : 0xFFFFFFFFu;
-                uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 8192u;
-                if (tail_max > 8192u) tail_max = 8192u;
+                uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 16384u;
+                if (tail_max > 16384u) tail_max = 16384u;
                 if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
                 static const uint32_t run_ahead = getenv("RT_RUN_AHEAD") ? (uint32_t)atoi(getenv("RT_RUN_AHEAD")) : 2u;
                 int cur = 0;
