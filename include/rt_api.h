@@ -255,8 +255,10 @@ int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, const double 
                       const int32_t *d_shard_ids, int32_t *d_full_ids, void *stream);
 
 /* Ray::trace (system.rs:122-133) for a batch of world-space rays (host
- * arrays, xyz interleaved; directions are used as given).  Ray i draws its
- * fog random numbers as pixel i, stratum 0, depth 0. */
+ * arrays, xyz interleaved).  Directions must have unit length, as every ray of
+ * the reference has (camera rays, scattered rays and Ray::transform all
+ * normalise): a direction off by more than 1e-9 is RT_ERR_INVALID.  Ray i draws
+ * its fog random numbers as pixel i, stratum 0, depth 0. */
 int rt_trace_rays(rt_scene *scene, uint64_t seed, uint64_t n, const double *origins, const double *directions,
                   rt_hit *hits, rt_stats *stats);
 

@@ -291,7 +291,8 @@ RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3
     const DevLeaf &F = sc.leaves[ob.frame];
     LeafRay ry = to_leaf(F, o, d);
     d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
-    const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d));
+    // object-space length per unit of world length (d need not have unit length: rt_trace_rays)
+    const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d)) / len3(d);
     const double bound = have_hit ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
     bool any = false;
     for (int mi = 0; mi < ob.n_meshes; ++mi) {
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                         } else {
                             o = xf_point(J.W, wo);
                             const d3 dl = xf_dir(J.W, wd);
-                            scale = len3(dl);
+                            scale = len3(dl) / len3(wd); // per unit of world length: wd need not be a unit vector
                             d = normalize3(dl);
                         }
                         wbound = best_obj >= 0 ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
@@ -1960,6 +1961,14 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     if (n > 0x7FFFFFFFull) {
         rt_host::set_last_error("rt_trace_rays: too many rays in one call");
         return RT_ERR_INVALID;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const double *dv = directions + 3 * i;
+        const double l2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+        if (!(std::fabs(l2 - 1.0) <= 2e-9)) {
+            rt_host::set_last_error("rt_trace_rays: direction " + std::to_string(i) + " does not have unit length");
+            return RT_ERR_INVALID;
+        }
     }
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_workspace(s, (size_t)n, 1);

@@ -254,6 +254,29 @@ def test_ray_batches_match_oracle(rt, name, center, radius):
     assert list(gst.guards) == list(rst.guards)
 
 
+@pytest.mark.parametrize("n_rays", [8000, 90000])     # wave-per-ray kernel; grid walk
+def test_ray_batches_several_meshes(rt, n_rays):
+    """Three meshes in two objects with their own frames, rays from everywhere around and inside them."""
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse_file(o, parity.scene_path("meshes2"), parity.ASSETS)
+    ro, rd = _random_rays(n_rays, 5, np.array([0.0, 1.0, 0.3]), 2.5)
+    dev = rt.DeviceScene(sc)
+    got, gst = dev.trace_rays(ro, rd, seed=4)
+    ref, rst = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    assert (ref["object"] == 2).mean() > 0.05 and (ref["object"] == 4).mean() > 0.02    # both mesh objects are hit
+    same_obj = got["object"] == ref["object"]
+    assert same_obj.mean() >= ID_MATCH_MIN, same_obj.mean()
+    hit = same_obj & (ref["object"] >= 0)
+    scale = np.maximum(1.0, np.abs(ref["t"][hit]))
+    assert np.mean(np.abs(got["t"][hit] - ref["t"][hit]) / scale < HIT_TOL) >= ID_MATCH_MIN
+    assert np.mean(np.all(np.abs(got["n"][hit] - ref["n"][hit]) < 1e-7, axis=1)) >= ID_MATCH_MIN
+    mesh_hit = hit & ((ref["object"] == 2) | (ref["object"] == 4))
+    assert np.mean(np.all(np.abs(got["uv"][mesh_hit] - ref["uv"][mesh_hit]) < 1e-7, axis=1)) >= ID_MATCH_MIN
+    # every ray of the reference has a unit direction; others are refused rather than traced differently
+    with pytest.raises(RuntimeError):
+        dev.trace_rays(ro[:4], rd[:4] * 2.0, seed=4)
+
+
 def test_reference_known_answers_on_device(rt):
     """The reference's own unit-test vectors, first hit through rt_trace_rays."""
     for case in GOLD["shape_intervals"]:
