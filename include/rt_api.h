@@ -220,7 +220,7 @@ typedef int (*rt_progress_cb)(void *user, uint32_t strata_done, uint32_t strata_
 /* ---- device path --------------------------------------------------------- */
 
 /* Replaces the construction of RenderContext (system.rs:272-278): deep-copies
- * the description onto the current HIP device, builds the per-mesh kd-tree and
+ * the description onto the current HIP device, builds the per-mesh grid and
  * the flattened per-object CSG programs. */
 int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);

@@ -346,8 +346,8 @@ __device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const D
 
 // Pass 1 of the nearest-hit search: every object except the triangle work.
 // A ray that passes the bounding box of a mesh object is appended to
-// `mesh_queue`; k_mesh then walks the kd-trees with full waves and merges its
-// result into the hit record.  CSG / MEDIUM prune code (and registers) the
+// `mesh_queue`; k_mesh then walks the mesh grids and merges its result into the
+// hit record.  CSG / MEDIUM prune code (and registers) the
 // scene does not need.
 struct HitRec {
     double t; // -1: nothing hit
@@ -903,11 +903,10 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
 #endif
 }
 
-// The same merge for a short queue: one wave per ray, every lane testing its share of the
-// triangles (the reference's brute force, mesh.rs:54-64, spread over 64 lanes), then a
-// wave-wide lexicographic min over (t, triangle index).  A lone wave needs ~100 dependent
-// kd-tree steps at memory latency; 36 independent triangle tests per lane finish in a few
-// microseconds, which is what the late, nearly empty bounce passes are made of.
+// The same merge for a short queue: one wave per ray (the reference's brute force, mesh.rs:54-64,
+// spread over 64 lanes and culled by group bounds), then a wave-wide lexicographic min over
+// (t, triangle index).  A lone walking lane takes ~100 microseconds over a grazing ray; a wave
+// on one ray takes a few, which is what the late, nearly empty bounce passes need.
 RT_DEV void wave_min_hit(double &t, uint32_t &tri)
 {
 #pragma unroll
@@ -1357,7 +1356,7 @@ struct rt_scene {
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
     uint64_t n_mesh_tris = 0;
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
-    uint32_t *mesh_queue = nullptr; // ray indices that need the kd-trees this pass
+    uint32_t *mesh_queue = nullptr; // ray indices that need the mesh walk this pass
     uint32_t *d_counts = nullptr; // 2 x (max_depth + 2): live rays per depth, then mesh-queue lengths per depth
     uint32_t counts_cap = 0;
     uint32_t *d_guards = nullptr; // 6
@@ -1578,7 +1577,7 @@ static int check_options(const rt_options *o)
 
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
-// nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the kd-tree pass
+// nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the mesh pass
 // returns 1 when the grid walk (k_mesh) ran, 0 otherwise; `mid` is recorded between the two stages
 static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
                             uint32_t *mesh_count, const PassParams &pp, int32_t *ids, hipEvent_t mid)
@@ -1602,7 +1601,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
     (void)hipEventRecord(mid, st);
     int walked = 0;
     if (s->has_mesh) {
-        // short queues: one wave per ray over all triangles; long queues: one lane per ray down the kd-tree
+        // short queues: one wave per ray over all triangles; long queues: one lane per ray through the mesh grid
         if ((uint64_t)live * s->n_mesh_tris <= (uint64_t)RT_BRUTE_MAX_TESTS) {
             uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
             if (blocks > 256 * 8) blocks = 256 * 8;
