@@ -77,6 +77,15 @@ struct DevObject {
     double density;
 };
 
+// 16-byte kd-tree node (the alternative to the grid, see k_mesh).  Interior: a = (right child << 2) | axis,
+// the left child is the next node.  Leaf: a = (first entry in the leaf-ordered records << 2) | 3,
+// b = triangle count.
+struct DevKdNode {
+    double split;
+    uint32_t a;
+    uint32_t b;
+};
+
 // One uniform grid per mesh.  The reference tests every triangle of a mesh
 // (mesh.rs:54-64); the grid only decides which triangles a ray visits.
 //  - occupancy words, one per 32 cells, x fastest: (bits, rank of the word's first
@@ -102,6 +111,8 @@ struct DevMesh {
     double cell[3], inv_cell[3];
     // groups of up to 64 neighbouring triangles for the wave-per-ray kernels (k_mesh_brute, k_tail)
     uint32_t grp0, n_groups;
+    uint32_t kd0;       // root node of this mesh's kd-tree (node indices inside it are mesh-relative)
+    uint32_t kd_index0; // base of this mesh's leaf-ordered triangle records
 };
 
 // One (mesh object, mesh) pair, in the order Ray::trace / Composite::intersect would visit them:
@@ -115,6 +126,7 @@ struct DevMeshJob {
     uint32_t n[3];
     uint32_t bits0, cell0, dist0;
     uint32_t tri0;    // into tris / tri_nrm
+    uint32_t kd0, kd_index0;
     uint32_t pad;
     DevXform W, O;    // the object's frame: world -> object, object -> world
     double qmin[3], qmax[3];
@@ -147,6 +159,8 @@ struct DevScene {
     const double *cell_tris; // 10 per (cell, triangle) reference, in cell order: the 9 above + the triangle index (low word)
     const uint32_t *tri_n; // 3 per triangle (normal indices, mesh-relative)
     const double *tri_nrm; // 9 per triangle: its three vertex normals
+    const DevKdNode *kd;     // kd-trees of all meshes
+    const double *leaf_tris; // 10 per kd leaf reference, in leaf order: v0, e1, e2, triangle index (low word)
     const double *grp_box;   // 6 per group: padded bounds (min xyz, max xyz)
     const double *grp_tris;  // 64 slots per group x 9: the triangle records in group order
     const uint32_t *grp_idx; // 64 slots per group: the triangle's index in its mesh, ~0u for an empty slot
@@ -173,4 +187,5 @@ struct DevScene {
 #define DEV_GRID_MAX_WORDS 2048 // occupancy words of all meshes together: 16 KB of LDS with their ranks, 32 KB of distances
 #define DEV_GRID_MAX_STARTS 6144 // cell_start entries kept in LDS (24 KB); beyond that they are read from memory
 #define DEV_GRID_MAX_AXIS 255
+#define DEV_KD_STACK 20       // kd-tree depth limit = LDS stack entries per lane
 #define DEV_MESH_JOBS_LDS 16 // job records kept in LDS (beyond that they are read from memory)

@@ -90,6 +90,181 @@ bool tri_touches_box(const double *v, const Box &cell, double pad)
     return n > 0;
 }
 
+// ---------------------------------------------------------------- kd-trees (the alternative to the grids)
+// One reference to a triangle inside a cell: the triangle and the bounds of the
+// part of it that lies in the cell ("split clipping": without it the diagonal,
+// chunky triangles of LinkedTorus.obj end up in ten leaves each and no empty
+// space is ever cut away).
+struct KdRef {
+    uint32_t tri;
+    Box box;
+};
+
+struct KdBuilder {
+    const std::vector<double> &verts; // 9 per triangle: v0, v1, v2 (absolute)
+    std::vector<DevKdNode> &nodes;
+    std::vector<uint32_t> &index;
+    uint32_t index_base; // start of this mesh's index list
+    int max_depth;
+    double pad;
+    double kIsect = 20.0, kTrav = 15.0, kEmptyBonus = 0.5; // chosen by measurement on MI355X
+    size_t leaf_max = 1;
+    double min_empty = 0.1;
+
+    // bounds of (triangle clipped to `cell` grown by pad); false if nothing is left
+    bool clip(uint32_t tri, const Box &cell, Box &out) const
+    {
+        double poly[16][3], tmp[16][3];
+        int n = 3;
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) poly[v][k] = verts[(size_t)tri * 9 + v * 3 + k];
+        for (int axis = 0; axis < 3 && n > 0; ++axis) {
+            for (int side = 0; side < 2 && n > 0; ++side) {
+                const double plane = side == 0 ? cell.lo[axis] - pad : cell.hi[axis] + pad;
+                int m = 0;
+                for (int i = 0; i < n; ++i) {
+                    const double *a = poly[i], *b = poly[(i + 1) % n];
+                    bool ina = side == 0 ? a[axis] >= plane : a[axis] <= plane;
+                    bool inb = side == 0 ? b[axis] >= plane : b[axis] <= plane;
+                    if (ina) {
+                        for (int k = 0; k < 3; ++k) tmp[m][k] = a[k];
+                        ++m;
+                    }
+                    if (ina != inb) {
+                        double t = (plane - a[axis]) / (b[axis] - a[axis]);
+                        for (int k = 0; k < 3; ++k) tmp[m][k] = a[k] + t * (b[k] - a[k]);
+                        tmp[m][axis] = plane;
+                        ++m;
+                    }
+                }
+                n = m;
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
+            }
+        }
+        if (n == 0) return false;
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] = poly[0][k];
+            out.hi[k] = poly[0][k];
+        }
+        for (int i = 1; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                out.lo[k] = std::fmin(out.lo[k], poly[i][k]);
+                out.hi[k] = std::fmax(out.hi[k], poly[i][k]);
+            }
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] -= pad;
+            out.hi[k] += pad;
+        }
+        return true;
+    }
+
+    void make_leaf(const std::vector<KdRef> &prims)
+    {
+        DevKdNode n;
+        n.split = 0.0;
+        n.a = (uint32_t)(((index.size() - index_base) << 2) | 3u);
+        n.b = (uint32_t)prims.size();
+        std::vector<uint32_t> sorted;
+        for (const KdRef &r : prims) sorted.push_back(r.tri);
+        std::sort(sorted.begin(), sorted.end());
+        index.insert(index.end(), sorted.begin(), sorted.end());
+        nodes.push_back(n);
+    }
+
+    void build(const std::vector<KdRef> &prims, const Box &box, int depth, int bad)
+    {
+        if (prims.size() <= leaf_max || depth >= max_depth) {
+            make_leaf(prims);
+            return;
+        }
+        double d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
+        double total_sa = 2.0 * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2]);
+        double inv_sa = total_sa > 0.0 ? 1.0 / total_sa : 0.0;
+        double old_cost = kIsect * (double)prims.size();
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1;
+        double best_split = 0.0;
+
+        struct Edge {
+            double t;
+            bool start;
+        };
+        std::vector<Edge> edges(prims.size() * 2);
+        for (int axis = 0; axis < 3; ++axis) {
+            for (size_t i = 0; i < prims.size(); ++i) {
+                edges[2 * i] = Edge{std::fmax(prims[i].box.lo[axis], box.lo[axis]), true};
+                edges[2 * i + 1] = Edge{std::fmin(prims[i].box.hi[axis], box.hi[axis]), false};
+            }
+            std::sort(edges.begin(), edges.end(), [](const Edge &a, const Edge &b) {
+                if (a.t == b.t) return (int)a.start > (int)b.start;
+                return a.t < b.t;
+            });
+            size_t n_below = 0, n_above = prims.size();
+            int o0 = (axis + 1) % 3, o1 = (axis + 2) % 3;
+            for (size_t i = 0; i < edges.size(); ++i) {
+                if (!edges[i].start) --n_above;
+                double t = edges[i].t;
+                if (t > box.lo[axis] && t < box.hi[axis]) {
+                    double below_sa = 2.0 * (d[o0] * d[o1] + (t - box.lo[axis]) * (d[o0] + d[o1]));
+                    double above_sa = 2.0 * (d[o0] * d[o1] + (box.hi[axis] - t) * (d[o0] + d[o1]));
+                    // the bonus for cutting away empty space applies only to a worthwhile slab:
+                    // sliver cuts would otherwise win every time and use up the depth budget
+                    double frac = n_below == 0 ? (t - box.lo[axis]) / d[axis] : (box.hi[axis] - t) / d[axis];
+                    double eb = ((n_above == 0 || n_below == 0) && frac >= min_empty) ? kEmptyBonus : 0.0;
+                    double cost = kTrav + kIsect * (1.0 - eb) *
+                                              (below_sa * inv_sa * (double)n_below + above_sa * inv_sa * (double)n_above);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = axis;
+                        best_split = t;
+                    }
+                }
+                if (edges[i].start) ++n_below;
+            }
+        }
+        if (best_cost > old_cost) ++bad;
+        if (best_axis < 0 || (best_cost > 4.0 * old_cost && prims.size() < 16) || bad >= 3) {
+            make_leaf(prims);
+            return;
+        }
+        Box bl = box, bh = box;
+        bl.hi[best_axis] = best_split;
+        bh.lo[best_axis] = best_split;
+        std::vector<KdRef> below, above;
+        for (const KdRef &r : prims) {
+            // A reference whose (padded) bounds merely touch the plane stays on its own side:
+            // candidate planes are exactly such bounds, and listing the touching triangle on
+            // both sides would duplicate one reference at every split.
+            bool lo_side = r.box.lo[best_axis] < best_split, hi_side = r.box.hi[best_axis] > best_split;
+            if (!lo_side && !hi_side) lo_side = true; // flat on the plane
+            if (lo_side && hi_side) {
+                KdRef c;
+                c.tri = r.tri;
+                if (clip(r.tri, bl, c.box)) below.push_back(c);
+                if (clip(r.tri, bh, c.box)) above.push_back(c);
+            } else if (lo_side) {
+                below.push_back(r);
+            } else {
+                above.push_back(r);
+            }
+        }
+        if (below.size() == prims.size() && above.size() == prims.size()) {
+            make_leaf(prims);
+            return;
+        }
+        size_t me = nodes.size();
+        DevKdNode n;
+        n.split = best_split;
+        n.a = (uint32_t)best_axis;
+        n.b = 0;
+        nodes.push_back(n);
+        build(below, bl, depth + 1, bad);
+        nodes[me].a = (uint32_t)((nodes.size() << 2) | (uint32_t)best_axis);
+        build(above, bh, depth + 1, bad);
+    }
+};
+
 // ---------------------------------------------------------------- flattening
 struct Flattener {
     const rt_scene_desc *d;
@@ -459,6 +634,14 @@ struct Flattener {
             }
         }
         out.cell_start.push_back((uint32_t)(out.cell_tris.size() / 10));
+        {
+            double n1 = 0.0, n2 = 0.0;
+            for (size_t c = 0; c < n_cells; ++c) {
+                n1 += (double)cells[c].size();
+                n2 += (double)cells[c].size() * (double)cells[c].size();
+            }
+            if (n1 > 0.0) out.grid_crowd = std::fmax(out.grid_crowd, n2 / n1);
+        }
         if (out.grid_bits.size() / 2 > DEV_GRID_MAX_WORDS) throw Err{RT_ERR_UNSUPPORTED, "mesh grids exceed the device budget"};
         // Groups of 64 triangles that lie together (Morton order of the centroids) with their padded
         // bounds: a wave that tests one ray against a whole mesh (k_mesh_brute, k_tail) first tests
@@ -500,6 +683,38 @@ struct Flattener {
                 }
                 for (int k = 0; k < 3; ++k) out.grp_box.push_back(lo[k] - 2.0 * pad);
                 for (int k = 0; k < 3; ++k) out.grp_box.push_back(hi[k] + 2.0 * pad);
+            }
+        }
+        // The alternative structure, built for every mesh as well (k_mesh<KD>, chosen per scene in
+        // rt_scene_create): a kd-tree with SAH + split clipping, 16-byte nodes, leaf-ordered records.
+        {
+            dm.kd0 = (uint32_t)out.kd.size();
+            dm.kd_index0 = (uint32_t)out.kd_index.size();
+            std::vector<DevKdNode> nodes; // mesh-relative node indices
+            int max_depth = (int)std::lround(8.0 + 1.3 * std::log2((double)std::max<uint32_t>(1u, m.n_triangles)));
+            if (max_depth > DEV_KD_STACK - 1) max_depth = DEV_KD_STACK - 1;
+            KdBuilder kb{tri_verts, nodes, out.kd_index, dm.kd_index0, max_depth, pad};
+            std::vector<KdRef> all(m.n_triangles);
+            for (uint32_t t = 0; t < m.n_triangles; ++t) {
+                all[t].tri = t;
+                for (int k = 0; k < 3; ++k) {
+                    all[t].box.lo[k] = pb[t].lo[k] - pad;
+                    all[t].box.hi[k] = pb[t].hi[k] + pad;
+                }
+            }
+            Box root;
+            for (int k = 0; k < 3; ++k) {
+                root.lo[k] = dm.bmin[k];
+                root.hi[k] = dm.bmax[k];
+            }
+            kb.build(all, root, 0, 0);
+            out.kd.insert(out.kd.end(), nodes.begin(), nodes.end());
+            for (size_t e = dm.kd_index0; e < out.kd_index.size(); ++e) {
+                const uint32_t t = out.kd_index[e];
+                for (int k = 0; k < 9; ++k) out.leaf_tris.push_back(out.tris[((size_t)dm.tri0 + t) * 9 + k]);
+                double tag = 0.0;
+                std::memcpy(&tag, &t, sizeof(t));
+                out.leaf_tris.push_back(tag);
             }
         }
         out.meshes.push_back(dm);
@@ -632,6 +847,8 @@ int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
                 j.cell0 = m.cell0;
                 j.dist0 = m.dist0;
                 j.tri0 = m.tri0;
+                j.kd0 = m.kd0;
+                j.kd_index0 = m.kd_index0;
                 j.W = F.W;
                 j.O = F.O;
                 out.jobs.push_back(j);

@@ -21,6 +21,9 @@ struct FlatScene {
     std::vector<uint32_t> tri_n;
     std::vector<double> tri_nrm;
     std::vector<DevMeshJob> jobs;
+    std::vector<DevKdNode> kd;
+    std::vector<uint32_t> kd_index;
+    std::vector<double> leaf_tris;
     std::vector<double> grp_box, grp_tris;
     std::vector<uint32_t> grp_idx;
     std::vector<double> normals;
@@ -31,6 +34,7 @@ struct FlatScene {
     double cam_fov_factor;
     double cam_c2w[16];
     bool uses_csg = false;
+    double grid_crowd = 0.0; // worst mesh: triangles in the cell of an average (cell, triangle) reference
 };
 
 // returns RT_OK or a negative rt_status with `err` filled

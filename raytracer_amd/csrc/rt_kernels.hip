@@ -567,27 +567,38 @@ __device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, 
         }                                                                                                              \
     } while (0)
 
+//
+// KD selects the other acceleration structure, a kd-tree per mesh: 16-byte nodes read with one
+// load, a front-to-back walk with the deferred far children on a per-lane stack in LDS (8-byte
+// entries: node and the far bound of its cell as an f32 rounded up; cells come in ray order, so
+// the near bound of a popped cell is the far bound of the leaf just finished), leaf triangles as
+// contiguous 80-byte records.  Everything around the walk - queue blocks, refill, job records,
+// the merge - is shared.  rt_scene_create picks the structure per scene.
+template <bool KD>
 __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
                                                       const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
                                                       uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
                                                       PassParams pp)
 {
-    extern __shared__ double4 mesh_lds[]; // job records, (bits, rank) pairs, distance words, then the cell starts if they fit
+    extern __shared__ double4 mesh_lds[]; // job records; then the grid tables, or the kd stacks
     const uint32_t n_jobs_lds = sc.n_jobs < DEV_MESH_JOBS_LDS ? sc.n_jobs : DEV_MESH_JOBS_LDS;
     DevMeshJob *jobs_lds = reinterpret_cast<DevMeshJob *>(mesh_lds);
     uint2 *grid_lds = reinterpret_cast<uint2 *>(jobs_lds + n_jobs_lds);
-    uint32_t *dist_lds = reinterpret_cast<uint32_t *>(grid_lds + sc.n_grid_words);
-    uint32_t *starts_lds = dist_lds + sc.n_dist_words;
-    const bool starts_in_lds = sc.n_cell_starts <= DEV_GRID_MAX_STARTS;
+    uint32_t *dist_lds = reinterpret_cast<uint32_t *>(grid_lds + (KD ? 0u : sc.n_grid_words));
+    uint32_t *starts_lds = dist_lds + (KD ? 0u : sc.n_dist_words);
+    const bool starts_in_lds = !KD && sc.n_cell_starts <= DEV_GRID_MAX_STARTS;
+    uint2 *stk = grid_lds + threadIdx.x; // KD: this lane's stack column, entry e at stk[e * RT_MESH_LANES]
     {
         const uint32_t *jw = reinterpret_cast<const uint32_t *>(sc.jobs);
         uint32_t *jl = reinterpret_cast<uint32_t *>(jobs_lds);
         for (uint32_t i = threadIdx.x; i < n_jobs_lds * (uint32_t)(sizeof(DevMeshJob) / 4); i += blockDim.x) jl[i] = jw[i];
-        const uint2 *gw = reinterpret_cast<const uint2 *>(sc.grid_bits);
-        for (uint32_t i = threadIdx.x; i < sc.n_grid_words; i += blockDim.x) grid_lds[i] = gw[i];
-        for (uint32_t i = threadIdx.x; i < sc.n_dist_words; i += blockDim.x) dist_lds[i] = sc.grid_dist[i];
-        if (starts_in_lds)
-            for (uint32_t i = threadIdx.x; i < sc.n_cell_starts; i += blockDim.x) starts_lds[i] = sc.cell_start[i];
+        if (!KD) {
+            const uint2 *gw = reinterpret_cast<const uint2 *>(sc.grid_bits);
+            for (uint32_t i = threadIdx.x; i < sc.n_grid_words; i += blockDim.x) grid_lds[i] = gw[i];
+            for (uint32_t i = threadIdx.x; i < sc.n_dist_words; i += blockDim.x) dist_lds[i] = sc.grid_dist[i];
+            if (starts_in_lds)
+                for (uint32_t i = threadIdx.x; i < sc.n_cell_starts; i += blockDim.x) starts_lds[i] = sc.cell_start[i];
+        }
     }
     __syncthreads();
 // job record `J` (an index): from LDS when it is one of the first DEV_MESH_JOBS_LDS
@@ -633,6 +644,11 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     double tmx = 0, tmy = 0, tmz = 0, w_tc = 0, t_end = 0;
     int cx = 0, cy = 0, cz = 0;
     uint32_t nx = 1, ny = 1, nz = 1, bits0 = 0, cell0 = 0, dist0 = 0;
+    // KD walk state: current node, stack height, the ray parameter range of the current cell; the tree's
+    // nodes and records (igx, igy, igz hold 1 / direction then)
+    uint32_t kd_node = 0u, kd0 = 0u, kidx0 = 0u;
+    int kd_sp = 0;
+    double kd_tmin = 0.0, kd_tmax = 0.0;
     double mt = 1.0e300;
     uint32_t mtri = 0xFFFFFFFFu;
 
@@ -736,6 +752,21 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     if (wbound < t1) t1 = wbound;
                     if (obj_found && obj_t < t1) t1 = obj_t; // a later mesh must be strictly nearer
                     if (t0 > t1) continue;
+                    if (KD) {
+                        igx = inv.x;
+                        igy = inv.y;
+                        igz = inv.z;
+                        kd0 = J.kd0;
+                        kidx0 = J.kd_index0;
+                        kd_node = 0u; // node indices are mesh-relative
+                        kd_sp = 0;
+                        kd_tmin = t0;
+                        kd_tmax = t1;
+                        mt = 1.0e300;
+                        mtri = 0xFFFFFFFFu;
+                        found = true;
+                        break;
+                    }
                     // enter the grid at t0
                     ogx = (o.x - J.bmin[0]) * J.inv_cell[0];
                     ogy = (o.y - J.bmin[1]) * J.inv_cell[1];
@@ -802,6 +833,79 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
         pf_lanes_walk += __popcll(__ballot(active));
 #endif
 
+        if (KD) {
+            // ------------------------------------------------------------ kd-tree: down to the next leaf, test it, pop
+            // "while-while": all lanes first walk down to their next leaf (cheap steps), then the wave
+            // tests triangles together (the expensive part).
+            if (active) {
+                const uint4 *__restrict__ kd = reinterpret_cast<const uint4 *>(sc.kd + kd0); // one 16-byte load per node
+                uint4 raw = kd[kd_node];
+                for (int step = 0; step < 64 && (raw.z & 3u) != 3u; ++step) { // depth <= DEV_KD_STACK
+                    const uint32_t axis = raw.z & 3u, right = raw.z >> 2;
+                    const double split = __hiloint2double((int)raw.y, (int)raw.x);
+                    const double oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+                    const double ia = axis == 0 ? igx : (axis == 1 ? igy : igz);
+                    const double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                    const double tplane = (split - oa) * ia;
+                    const bool below_first = (oa < split) || (oa == split && da <= 0.0);
+                    const uint32_t first = below_first ? kd_node + 1u : right;
+                    const uint32_t second = below_first ? right : kd_node + 1u;
+                    // slack: a hit within rounding distance of the plane is searched on both sides
+                    const double eps = 1e-9 * (fabs(tplane) + 1.0);
+                    const bool only_first = (tplane > kd_tmax + eps) || (tplane <= 0.0);
+                    const bool only_second = !only_first && (tplane < kd_tmin - eps);
+                    if (!only_first && !only_second) {
+                        if (kd_sp < DEV_KD_STACK) {
+                            stk[kd_sp * RT_MESH_LANES] = make_uint2(second, __float_as_uint(__double2float_ru(kd_tmax)));
+                            ++kd_sp;
+                        }
+                        kd_tmax = tplane + eps;
+                    }
+                    kd_node = only_second ? second : first;
+                    raw = kd[kd_node];
+                }
+                PF_MARK(pf_walk);
+                if ((raw.z & 3u) == 3u) {
+                    const uint32_t first = kidx0 + (raw.z >> 2), last = first + raw.w;
+                    const double2 *__restrict__ rec = reinterpret_cast<const double2 *>(sc.leaf_tris + (size_t)first * 10);
+                    for (uint32_t e = first; e < last; e += RT_MESH_BATCH, rec += 5 * RT_MESH_BATCH) {
+                        double2 r[RT_MESH_BATCH][5];
+#pragma unroll
+                        for (int b = 0; b < RT_MESH_BATCH; ++b) {
+                            const double2 *src = (e + (uint32_t)b < last) ? rec + 5 * b : rec; // past the end: repeat the first
+#pragma unroll
+                            for (int c = 0; c < 5; ++c) r[b][c] = src[c];
+                        }
+#pragma unroll
+                        for (int b = 0; b < RT_MESH_BATCH; ++b) {
+                            const d3 v0 = mk3(r[b][0].x, r[b][0].y, r[b][1].x), e1 = mk3(r[b][1].y, r[b][2].x, r[b][2].y),
+                                     e2 = mk3(r[b][3].x, r[b][3].y, r[b][4].x);
+                            const uint32_t ti = (uint32_t)__double2loint(r[b][4].y);
+                            double t, u, v;
+                            if (tri_hit_v(v0, e1, e2, o, d, t, u, v)) {
+                                if (t < mt || (t == mt && ti < mtri)) { // a repeated record cannot beat itself
+                                    mt = t;
+                                    mtri = ti;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (kd_sp == 0) {
+                    active = false;
+                } else {
+                    --kd_sp;
+                    const uint2 e = stk[kd_sp * RT_MESH_LANES];
+                    kd_node = e.x;
+                    // the stored bounds are f32 round-ups: step back by more than that rounding
+                    kd_tmin = kd_tmax - (2.4e-7 * fabs(kd_tmax) + 1e-9);
+                    kd_tmax = (double)__uint_as_float(e.y);
+                    if (mt < kd_tmin) active = false; // every remaining cell lies beyond the hit
+                }
+            }
+            PF_MARK(pf_test);
+            continue;
+        }
         // ---------------------------------------------------------------- walk to the next occupied cell
         // "while-while": all lanes first move to their next occupied cell (LDS only), then the wave
         // tests triangles together (the expensive part).
@@ -1356,6 +1460,8 @@ struct rt_scene {
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
     uint64_t n_mesh_tris = 0;
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
+    bool mesh_kd = false;           // walk kd-trees instead of grids (chosen in rt_scene_create)
+    uint32_t mesh_kd_lds_bytes = 0; // dynamic LDS of k_mesh<KD>: job records + stacks
     uint32_t *mesh_queue = nullptr; // ray indices that need the mesh walk this pass
     uint32_t *d_counts = nullptr; // 2 x (max_depth + 2): live rays per depth, then mesh-queue lengths per depth
     uint32_t counts_cap = 0;
@@ -1491,6 +1597,22 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     s->dev.n_cell_starts = (uint32_t)flat.cell_start.size();
     s->dev.n_dist_words = (uint32_t)flat.grid_dist.size();
     s->dev.n_jobs = (uint32_t)flat.jobs.size();
+    if ((rc = upload(s, flat.kd, &s->dev.kd))) return fail(rc);
+    if ((rc = upload(s, flat.leaf_tris, &s->dev.leaf_tris))) return fail(rc);
+    s->mesh_kd_lds_bytes = (uint32_t)(std::min<size_t>(flat.jobs.size(), DEV_MESH_JOBS_LDS) * sizeof(DevMeshJob)) +
+                           DEV_KD_STACK * RT_MESH_LANES * (uint32_t)sizeof(uint2);
+    {
+        // Structure per scene.  The grid is the default (same speed on LinkedTorus.obj, no stack, a
+        // trivial builder); it degrades when a mesh crowds many triangles into few cells, which the
+        // tree's SAH splits handle.  RT_ACCEL=grid|kd overrides (measurements, tests).
+        const double crowd = flat.grid_crowd; // triangles in the cell of an average (cell, triangle) reference, worst mesh
+        s->mesh_kd = crowd > 24.0;            // LinkedTorus.obj: 7; Monkey.obj: 5
+        if (const char *e = getenv("RT_ACCEL")) {
+            if (!strcmp(e, "kd")) s->mesh_kd = true;
+            if (!strcmp(e, "grid")) s->mesh_kd = false;
+        }
+        RT_TRACE("mesh structure: %s (a triangle shares its grid cell with %.1f on average)", s->mesh_kd ? "kd-tree" : "grid", crowd);
+    }
     s->mesh_lds_bytes = (uint32_t)(std::min<size_t>(flat.jobs.size(), DEV_MESH_JOBS_LDS) * sizeof(DevMeshJob)) +
                         s->dev.n_grid_words * 8u + s->dev.n_dist_words * 4u +
                         (s->dev.n_cell_starts <= DEV_GRID_MAX_STARTS ? s->dev.n_cell_starts * 4u : 0u);
@@ -1618,8 +1740,12 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             uint64_t mb = ((uint64_t)live + per_wg - 1) / per_wg;
             if (mb < 1) mb = 1;
             if (mb > max_wgs) mb = max_wgs;
-            hipLaunchKernelGGL(k_mesh, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_lds_bytes, st, s->dev, q,
-                               s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+            if (s->mesh_kd)
+                hipLaunchKernelGGL(k_mesh<true>, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_kd_lds_bytes, st, s->dev, q,
+                                   s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+            else
+                hipLaunchKernelGGL(k_mesh<false>, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_lds_bytes, st, s->dev, q,
+                                   s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp);
             walked = 1;
         }
     }

@@ -97,6 +97,65 @@ def test_row_major_output_equals_unsharded(rt):
         dev.render_shard(o, 0, 2, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream, row_major=True)
 
 
+@pytest.mark.parametrize("name", ["mesh", "meshes2"])
+def test_kd_tree_walk_matches_oracle_and_grid(rt, monkeypatch, name):
+    """The other mesh structure of k_mesh (RT_ACCEL=kd: SAH kd-trees, LDS stacks): same image as the
+    oracle, and bit for bit the image of the grid walk - both only choose which triangles get the
+    reference's test."""
+    o = rt.Options(width=240, height=180, samples=4, seed=13)
+    sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+    monkeypatch.setenv("RT_ACCEL", "grid")
+    g_rgb, g_ids, g_st = rt.DeviceScene(sc).render(o)
+    monkeypatch.setenv("RT_ACCEL", "kd")
+    dev = rt.DeviceScene(sc)
+    rgb, ids, st = dev.render(o)
+    assert np.array_equal(rgb, g_rgb) and np.array_equal(ids, g_ids) and st.rays == g_st.rays
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
+    ro, rd = _random_rays(90000, 8, np.array([0.0, 1.0, 0.0]), 2.5)
+    got, _ = dev.trace_rays(ro, rd, seed=4)
+    want, _ = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    same = got["object"] == want["object"]
+    assert same.mean() >= ID_MATCH_MIN
+    hit = same & (want["object"] >= 0)
+    assert np.mean(np.abs(got["t"][hit] - want["t"][hit]) / np.maximum(1.0, np.abs(want["t"][hit])) < HIT_TOL) >= ID_MATCH_MIN
+
+
+def test_crowded_mesh_teapot_in_a_stadium(rt, tmp_path, monkeypatch):
+    """A mesh whose triangles crowd into a corner of its bounds (1500 small ones in a 0.3 box on a
+    60 x 60 ground quad): the uniform grid puts hundreds of them into single cells, the scene then
+    defaults to the kd-tree; both structures must still give the oracle's image."""
+    rng = np.random.default_rng(3)
+    lines = ["o Stadium", "v -30 0 -30", "v 30 0 -30", "v 30 0 30", "v -30 0 30", "vn 0 1 0"]
+    faces = ["f 1//1 3//1 2//1", "f 1//1 4//1 3//1"]                  # wound to face +y
+    nv = 4
+    for _ in range(1500):
+        c = np.array([0.0, 0.4, 0.0]) + rng.uniform(-0.15, 0.15, 3)
+        p = c + rng.uniform(-0.03, 0.03, (3, 3))
+        for q in p:
+            lines.append("v %.6f %.6f %.6f" % tuple(q))
+        faces.append("f %d//1 %d//1 %d//1" % (nv + 1, nv + 2, nv + 3))
+        nv += 3
+    (tmp_path / "stadium.obj").write_text("\n".join(lines + ["s 1"] + faces) + "\n")
+    text = """options { background color rgb <0.4, 0.5, 0.7> }
+camera { origin <0.6, 0.9, 1.2> look_at <0, 0.4, 0> }
+object "light" { sphere { origin <4, 6, 3> radius 2 } material { diffuse_light intensity 4 texture { solid color white } } }
+object "stadium" { mesh { file "stadium.obj" } material { lambertian texture { solid color rgb <0.8, 0.6, 0.4> } } }
+"""
+    o = rt.Options(width=200, height=150, samples=1, seed=2)
+    sc = rt.parse(o, text, str(tmp_path))
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert (rids == 1).mean() > 0.5
+    images = []
+    for accel in (None, "grid", "kd"):
+        if accel:
+            monkeypatch.setenv("RT_ACCEL", accel)
+        rgb, ids, st = rt.DeviceScene(sc).render(o)
+        _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
+        images.append(rgb)
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[1], images[2])
+
+
 def test_stats_account_for_every_stage(rt):
     """rt_stats: per-kernel times from HIP events, ray and mesh-queue counts; the tail kernel's rays are counted."""
     o = rt.Options(width=256, height=192, samples=1, seed=4)
