@@ -1343,18 +1343,23 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
 template <bool CSG, bool MEDIUM, bool TORUS>
 __global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
-                                                    double *fb, PassParams pp, uint32_t *guards_out, int has_mesh)
+                                                    double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
+                                                    uint32_t *lane_totals)
 {
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     const uint32_t count = counts[pp.depth];
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    // a scene with meshes: one wave per path (the 64 lanes share the mesh test); without: one lane per path
+    const bool per_lane = !has_mesh;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
+    const uint32_t unit = per_lane ? tid : tid >> 6, n_units = per_lane ? n_threads : n_threads >> 6;
+    const bool writer = per_lane || lane_id() == 0u;
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
     Guards gd;
     for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
     gd.overflow = 0u;
-    for (uint32_t i = wave; i < count; i += n_waves) {
+    uint32_t my_rays = 0u, my_depth = 0u; // per_lane: segments traced beyond the first, deepest level reached
+    for (uint32_t i = unit; i < count; i += n_units) {
         d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
         d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
         d3 thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
@@ -1376,7 +1381,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, 
             d3 X;
             const bool alive = shade_one(sc, o, d, thr, pixel, h, p, bg, X);
             if (!alive) {
-                if (lane_id() == 0u) {
+                if (writer) {
                     double *px = fb + (size_t)slot * 3;
                     px[0] += thr.x * X.x;
                     px[1] += thr.y * X.y;
@@ -1385,10 +1390,31 @@ __global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, 
                 break;
             }
             ++p.depth;
-            if (lane_id() == 0u) atomicAdd(&counts_out[p.depth], 1u);
+            // rays per depth level: one atomic per segment is fine for a wave per path; lanes
+            // would hammer a few words, so they keep a total and the deepest level instead
+            if (per_lane) {
+                ++my_rays;
+                my_depth = p.depth > my_depth ? p.depth : my_depth;
+            } else if (writer) {
+                atomicAdd(&counts_out[p.depth], 1u);
+            }
         }
     }
-    if (lane_id() == 0u) { // every lane counted the same events
+    if (per_lane) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            my_rays += __shfl_xor(my_rays, off);
+            const uint32_t od = __shfl_xor(my_depth, off);
+            my_depth = od > my_depth ? od : my_depth;
+            for (int k = 0; k < 5; ++k) gd.g[k] += __shfl_xor(gd.g[k], off);
+            gd.overflow += __shfl_xor(gd.overflow, off);
+        }
+        if (lane_id() == 0u) {
+            if (my_rays) atomicAdd(&lane_totals[0], my_rays);
+            if (my_depth) atomicMax(&lane_totals[1], my_depth);
+        }
+    }
+    if (lane_id() == 0u) { // wave per path: every lane counted the same events; lane per path: summed above
         for (int k = 0; k < 5; ++k)
             if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
         if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
@@ -1529,7 +1555,7 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
     if (max_depth + 2 > s->counts_cap) {
         if (s->d_counts) (void)hipFree(s->d_counts);
         s->d_counts = nullptr;
-        HIP_TRY(hipMalloc((void **)&s->d_counts, 2 * (max_depth + 2) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s->d_counts, (2 * (max_depth + 2) + 2) * sizeof(uint32_t))); // + k_tail's lane totals
         if (s->h_pinned) (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
         HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (3 * (max_depth + 2) + 8) * sizeof(uint32_t), hipHostMallocDefault));
@@ -1756,12 +1782,12 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
 
 static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const PassParams &pp, double *d_rgb)
 {
-    uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
+    uint64_t blocks = ((uint64_t)live * (s->has_mesh ? 64 : 1) + RT_BLOCK - 1) / RT_BLOCK; // wave or lane per path
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
 #define LAUNCH_T(C, M, T)                                                                                              \
     hipLaunchKernelGGL((k_tail<C, M, T>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, s->d_counts,       \
-                       s->d_counts, d_rgb, pp, s->d_guards, s->has_mesh ? 1 : 0)
+                       s->d_counts, d_rgb, pp, s->d_guards, s->has_mesh ? 1 : 0, s->d_counts + 2 * (pp.max_depth + 2))
     const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
     switch (variant) {
     case 0: LAUNCH_T(false, false, false); break;
@@ -1835,7 +1861,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 hipLaunchKernelGGL(k_fill_background, dim3((n_slots + 255) / 256), dim3(256), 0, st, s->dev, g, rank,
                                    n_slots, d_rgb, row_major ? 1 : 0);
             } else {
-                HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * (opts->max_depth + 2) * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetAsync(s->d_counts, 0, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t), st));
                 // depth 0 reads no ray queue: entry i is slot i and its camera ray is regenerated in place
                 RayQueue q_primary = s->q[0];
                 q_primary.primary = 1;
@@ -1903,8 +1929,8 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                         break;
                     }
                 }
-                HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, 2 * (opts->max_depth + 2) * sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, st)); // rays per depth, then mesh-queue lengths per depth
+                HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, st)); // rays per depth, mesh-queue lengths per depth, lane totals
                 HIP_TRY(hipStreamSynchronize(st));
                 std::vector<uint32_t> mesh_counts(opts->max_depth + 1, 0u);
                 for (uint32_t k = 0; k <= opts->max_depth; ++k) mesh_counts[k] = s->h_pinned[opts->max_depth + 2 + k];
@@ -1923,10 +1949,18 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     s->h_pinned[0] = (uint32_t)valid;
                 }
                 local.primary_rays += s->h_pinned[0];
+                uint32_t levels = 0;
                 for (uint32_t k = 0; k < opts->max_depth; ++k) {
                     local.rays += s->h_pinned[k];
-                    if (s->h_pinned[k]) local.bounce_passes++;
+                    if (s->h_pinned[k]) ++levels;
                 }
+                {
+                    // a lane-per-path tail reports its segments as a total and its deepest level
+                    const uint32_t *lane_totals = s->h_pinned + 2 * (opts->max_depth + 2);
+                    local.rays += lane_totals[0];
+                    if (lane_totals[0] && lane_totals[1] + 1 > levels) levels = lane_totals[1] + 1;
+                }
+                if (levels > local.bounce_passes) local.bounce_passes = levels; // (strata share the levels)
                 {
                     float ms_k = 0.f;
                     HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[0], s->evp[1]));

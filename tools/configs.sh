@@ -1,0 +1,17 @@
+#!/bin/bash
+# BASELINE.json's other configurations on one GPU: one bench line each -> gpurun_out/configs.jsonl
+cd $GRAFT_REPO_ROOT
+: > gpurun_out/configs.jsonl
+run() { timeout -k 10 280 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grep '"metric"' >> gpurun_out/configs.jsonl || echo "FAILED: $*"; }
+run --scene cornell_box --width 1920 --height 1080 --steps 5 --warmup 1
+run --scene torus --width 3840 --height 2160 --steps 5 --warmup 1
+run --scene csg --width 3840 --height 2160 --steps 5 --warmup 1
+run --scene three-spheres --width 3840 --height 2160 --steps 5 --warmup 1
+run --scene room --width 3840 --height 2160 --steps 3 --warmup 1
+run --scene fog_light --width 7680 --height 4320 --samples 16 --steps 1 --warmup 1
+python - <<'PY'
+import json
+for l in open("gpurun_out/configs.jsonl"):
+    j = json.loads(l)
+    print("%-70s %8.0f Mrays/s %9.2f ms/frame  stages %s" % (j["config"]["workload"], j["value"], j["ms_per_step"], {k: round(v, 2) for k, v in j["stage_ms_per_step"].items()}))
+PY
