@@ -73,8 +73,10 @@ struct DevObject {
     int32_t mesh0, n_meshes;
     int32_t material;
     int32_t needs_uv; // material's texture reads uv
-    int32_t pad;
+    int32_t has_bounds; // wmin/wmax hold world bounds of all leaves (DO_CSG, DO_MEDIUM, a torus leaf): a ray that
+                        // misses them meets no leaf, so the object is skipped without running its program
     double density;
+    double wmin[3], wmax[3];
 };
 
 // 16-byte kd-tree node (the alternative to the grid, see k_mesh).  Interior: a = (right child << 2) | axis,

@@ -780,6 +780,59 @@ struct Flattener {
         obj.prog_len = (int)out.prog.size() - obj.prog0;
         if (obj.kind == DO_MEDIUM && obj.prog_len == 1) obj.prog_len = 0; // single boundary leaf
         if (obj.kind == DO_LEAF) obj.prog_len = 0;
+        // world bounds of all leaves, for the objects whose evaluation is expensive
+        bool wants_bounds = obj.kind == DO_CSG || obj.kind == DO_MEDIUM;
+        for (int li = obj.leaf0; li < obj.leaf0 + obj.n_leaves; ++li)
+            wants_bounds = wants_bounds || out.leaves[li].kind == DL_TORUS;
+        if (wants_bounds && obj.kind != DO_MESH) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool bounded = obj.n_leaves > 0;
+            for (int li = obj.leaf0; li < obj.leaf0 + obj.n_leaves && bounded; ++li) {
+                const DevLeaf &L = out.leaves[li];
+                const double *p = L.p;
+                double b[6]; // leaf-space min xyz, max xyz
+                switch (L.kind) {
+                case DL_NONE: continue; // a frame, no surface
+                case DL_SPHERE: {
+                    const double r = std::sqrt(p[3]);
+                    for (int k = 0; k < 3; ++k) {
+                        b[k] = p[k] - r;
+                        b[3 + k] = p[k] + r;
+                    }
+                    break;
+                }
+                case DL_RECT_XY: b[0] = p[4], b[3] = p[5], b[1] = p[6], b[4] = p[7], b[2] = b[5] = p[2]; break;
+                case DL_RECT_XZ: b[0] = p[4], b[3] = p[5], b[2] = p[6], b[5] = p[7], b[1] = b[4] = p[1]; break;
+                case DL_RECT_ZY: b[2] = p[4], b[5] = p[5], b[1] = p[6], b[4] = p[7], b[0] = b[3] = p[0]; break;
+                case DL_CUBE: b[0] = p[0], b[3] = p[5], b[1] = p[10], b[4] = p[15], b[2] = p[20], b[5] = p[25]; break;
+                case DL_CYLINDER: // whichever way the axis is placed along y
+                    b[0] = b[2] = -p[0], b[3] = b[5] = p[0], b[1] = -std::fabs(p[1]), b[4] = std::fabs(p[1]);
+                    break;
+                case DL_TORUS: {
+                    const double r = std::fabs(p[0]) + std::fabs(p[1]);
+                    for (int k = 0; k < 3; ++k) b[k] = -r, b[3 + k] = r;
+                    break;
+                }
+                default: bounded = false; continue; // a plane: no bounds
+                }
+                for (int c = 0; c < 8; ++c) {
+                    const double q[3] = {b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]};
+                    for (int k = 0; k < 3; ++k) {
+                        const double w = L.identity ? q[k] : q[0] * L.O.m[0 * 3 + k] + q[1] * L.O.m[1 * 3 + k] + q[2] * L.O.m[2 * 3 + k] + L.O.m[9 + k];
+                        lo[k] = std::fmin(lo[k], w);
+                        hi[k] = std::fmax(hi[k], w);
+                    }
+                }
+            }
+            if (bounded && lo[0] <= hi[0]) {
+                obj.has_bounds = 1;
+                for (int k = 0; k < 3; ++k) {
+                    const double padk = 1e-7 * (std::fmax(std::fabs(lo[k]), std::fabs(hi[k])) + 1.0);
+                    obj.wmin[k] = lo[k] - padk;
+                    obj.wmax[k] = hi[k] + padk;
+                }
+            }
+        }
         out.objects.push_back(obj);
     }
 };

@@ -366,12 +366,28 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
     double best_t = DBL_MAX;
     int best_obj = -1;
     uint32_t best_aux = 0u;
+    const d3 inv_w = (CSG || MEDIUM || TORUS) ? mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z) : mk3(0, 0, 0);
     for (int k = 0; k < sc.n_objects; ++k) {
         const DevObject &ob = sc.objects[k];
         Candidate c;
         c.ok = false;
         c.t = 0.0;
         c.aux = 0u;
+        if ((CSG || MEDIUM || TORUS) && ob.has_bounds) {
+            // the expensive objects (CSG programs, fog boundaries, tori) carry the world bounds of all
+            // their leaves: a ray that misses those, or has them behind it, meets no leaf at t >= 0
+            double t0 = 0.0, t1 = 1.0e300; // NaNs (0 * inf) drop out of fmin / fmax: the box then counts as met
+            const double ax = (ob.wmin[0] - o.x) * inv_w.x, bx = (ob.wmax[0] - o.x) * inv_w.x;
+            t0 = fmax(t0, fmin(ax, bx));
+            t1 = fmin(t1, fmax(ax, bx));
+            const double ay = (ob.wmin[1] - o.y) * inv_w.y, by = (ob.wmax[1] - o.y) * inv_w.y;
+            t0 = fmax(t0, fmin(ay, by));
+            t1 = fmin(t1, fmax(ay, by));
+            const double az = (ob.wmin[2] - o.z) * inv_w.z, bz = (ob.wmax[2] - o.z) * inv_w.z;
+            t0 = fmax(t0, fmin(az, bz));
+            t1 = fmin(t1, fmax(az, bz));
+            if (t0 > t1 + 1e-9 * (fabs(t1) + 1.0)) continue;
+        }
         switch (ob.kind) {
         case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
         case DO_CSG:
