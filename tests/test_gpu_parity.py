@@ -156,6 +156,28 @@ object "stadium" { mesh { file "stadium.obj" } material { lambertian texture { s
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[1], images[2])
 
 
+def test_scene_too_large_for_lds_tables(rt):
+    """120 objects: the scene tables (objects, leaves) exceed the 32 KB the kernels stage in LDS, so
+    they are read from memory; same paths either way."""
+    rng = np.random.default_rng(9)
+    shapes = [{"kind": "plane", "params": [0, -1.2, 0, 0, 1, 0]}]
+    for i in range(119):
+        c = rng.uniform([-3, -1, -9], [3, 2, -4])
+        if i % 3:
+            shapes.append({"kind": "sphere", "params": [*c, 0.25]})
+        else:
+            shapes.append({"kind": "cube", "params": [*(c - 0.2), *(c + 0.2)]})
+    d = descs.Desc(shapes)
+    for k in range(3):
+        d.desc.background[k] = [0.6, 0.7, 0.9][k]
+    o = rt.Options(width=160, height=120, samples=1, seed=6, max_depth=8)
+    sc = descs.FakeScene(d)
+    rgb, ids, st = rt.DeviceScene(sc).render(o)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert len(np.unique(rids)) > 30
+    _check(parity.compare(rgb, ids, ref, rids, 1), st, rst)
+
+
 def test_stats_account_for_every_stage(rt):
     """rt_stats: per-kernel times from HIP events, ray and mesh-queue counts; the tail kernel's rays are counted."""
     o = rt.Options(width=256, height=192, samples=1, seed=4)
