@@ -156,6 +156,29 @@ object "stadium" { mesh { file "stadium.obj" } material { lambertian texture { s
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[1], images[2])
 
 
+def test_many_mesh_objects(rt):
+    """18 mesh objects of two meshes each = 36 (object, mesh) job records: more than k_mesh keeps in LDS,
+    and the grid cell budget is split 36 ways."""
+    text = ["options { background color rgb <0.5, 0.6, 0.8> }", "camera { origin <0, 6, 12> look_at <0, 1, 0> }",
+            'object "floor" { plane { origin <0, 0, 0> normal <0, 1, 0> } material { lambertian texture { solid color rgb <0.6, 0.6, 0.6> } } }']
+    for i in range(18):
+        x, z = (i % 6) * 2.4 - 6.0, (i // 6) * 3.0 - 3.0
+        text.append('object { mesh { file "two_parts.obj" transform { rotate_y %d translate <%.1f, 1.1, %.1f> } } '
+                    "material { lambertian texture { solid color rgb <0.9, %.2f, 0.3> } } }" % (17 * i, x, z, 0.2 + 0.04 * i))
+    o = rt.Options(width=240, height=160, samples=1, seed=5, max_depth=6)
+    sc = rt.parse(o, "\n".join(text), parity.ASSETS)
+    assert sc.desc.contents.n_meshes == 36
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert len(np.unique(rids)) >= 18
+    dev = rt.DeviceScene(sc)
+    rgb, ids, st = dev.render(o)
+    _check(parity.compare(rgb, ids, ref, rids, 1), st, rst)
+    ro, rd = _random_rays(120000, 3, np.array([0.0, 1.0, 0.0]), 5.0)      # long queue: the grid walk
+    got, _ = dev.trace_rays(ro, rd, seed=4)
+    want, _ = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    assert (got["object"] == want["object"]).mean() >= ID_MATCH_MIN
+
+
 def test_scene_too_large_for_lds_tables(rt):
     """120 objects: the scene tables (objects, leaves) exceed the 32 KB the kernels stage in LDS, so
     they are read from memory; same paths either way."""
