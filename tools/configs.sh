@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 : > gpurun_out/configs.jsonl
 run() { timeout -k 10 280 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grep '"metric"' >> gpurun_out/configs.jsonl || echo "FAILED: $*"; }
 run --scene cornell_box --width 1920 --height 1080 --steps 5 --warmup 1
+run --scene mesh_monkey --width 3840 --height 2160 --steps 5 --warmup 1
 run --scene torus --width 3840 --height 2160 --steps 5 --warmup 1
 run --scene csg --width 3840 --height 2160 --steps 5 --warmup 1
 run --scene three-spheres --width 3840 --height 2160 --steps 5 --warmup 1
