@@ -1,0 +1,169 @@
+// rt_k_common.h — wavefront buffers, queue appends, LDS staging of the scene tables, camera rays
+// (device code of librt_amd.so; included by rt_kernels.hip, which holds the host side of the C ABI)
+#pragma once
+
+// ------------------------------------------------------------------ device buffers
+struct RayQueue {
+    double *o[3];
+    double *d[3];
+    double *thr[3];
+    uint32_t *slot;  // index into the shard's frame buffer
+    uint32_t *pixel; // y * width + x, the random-number key
+    // primary != 0: nothing above is read.  Entry i is slot i of the shard and its ray is that
+    // pixel's camera ray, regenerated wherever it is needed (a jitter draw and a normalise) instead
+    // of being written by one kernel and read back by three: 1.8 GB less traffic per 4K frame.
+    int primary;
+    int row_major; // outputs are indexed by pixel instead of by shard slot (RT_FLAG_ROW_MAJOR)
+    uint32_t rank, s_i, s_j;
+    rt_shard_geom g;
+    double recip_sqrt_spp;
+};
+
+struct HitBuf {
+    double *t;
+    double *n[3];
+    double *uv[2];
+    int32_t *obj;
+};
+
+#ifndef RT_MESH_BATCH
+#define RT_MESH_BATCH 2
+#endif
+#ifndef RT_MESH_WAVES
+#define RT_MESH_WAVES 3
+#endif
+#define RT_MESH_OCC __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, RT_MESH_WAVES)))
+
+// k_intersect streams rays in and hit records out: without CSG it is worth 4 waves per SIMD (a few
+// spilled registers against twice the loads in flight: 1.06 -> 0.87 ms per 4K frame, measured)
+#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu((CSG || TORUS) ? 1 : 4)))
+
+struct PassParams {
+    uint64_t seed;
+    uint32_t stratum;
+    uint32_t depth;
+    uint32_t max_depth;
+    uint32_t force_uv;
+    double bias;
+};
+
+#define RT_BLOCK 256
+
+RT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Append with one atomic per workgroup: a single counter word takes about 90 atomics per
+// microsecond on this chip, so a per-wave atomic caps a pass at ~6 G appended rays/s; with
+// 1024-thread workgroups the counter is out of the picture.  Called by every thread of the
+// block, in block-uniform control flow.  `lds` holds blockDim.x / 64 + 1 words.
+RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
+{
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (lane_id() == 0) lds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; ++w) {
+            uint32_t c = lds[w];
+            lds[w] = total;
+            total += c;
+        }
+        lds[n_waves] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t at = lds[n_waves] + lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+    __syncthreads();
+    return at;
+}
+
+#define RT_BLOCK_WIDE 1024 // ray generation and shading: light on registers, heavy on queue appends
+
+// The scene's small tables (objects, leaves, meshes, materials, textures) are read by every ray
+// through chains of dependent loads: objects[k] -> leaves[leaf0] -> parameters.  From memory each
+// link costs a cache round trip of several hundred cycles - measured, the object loop of
+// k_intersect waited 27 000 cycles per 64 rays on them.  Each workgroup therefore copies the
+// tables into LDS once and the kernel works on a DevScene whose pointers lead there.  Scenes whose
+// tables exceed RT_SCENE_LDS_MAX keep reading memory.  Ends with a barrier.
+#define RT_SCENE_LDS_MAX 32768u
+static inline __host__ __device__ uint32_t scene_lds_bytes(const DevScene &sc)
+{
+    const uint32_t b = (((uint32_t)sc.n_objects * (uint32_t)sizeof(DevObject) + 15u) & ~15u) +
+                       ((sc.n_leaves * (uint32_t)sizeof(DevLeaf) + 15u) & ~15u) +
+                       ((sc.n_meshes * (uint32_t)sizeof(DevMesh) + 15u) & ~15u) +
+                       ((sc.n_materials * (uint32_t)sizeof(DevMaterial) + 15u) & ~15u) +
+                       ((sc.n_textures * (uint32_t)sizeof(DevTexture) + 15u) & ~15u);
+    return b <= RT_SCENE_LDS_MAX ? b : 0u;
+}
+
+RT_DEV DevScene scene_in_lds(const DevScene &sc, unsigned char *lds)
+{
+    DevScene v = sc;
+    if (scene_lds_bytes(sc) != 0u) {
+        unsigned char *p = lds;
+#define RT_STAGE(FIELD, TYPE, COUNT)                                                                                   \
+    do {                                                                                                               \
+        const uint32_t words_ = (uint32_t)(COUNT) * (uint32_t)(sizeof(TYPE) / 4);                                      \
+        const uint32_t *src_ = reinterpret_cast<const uint32_t *>(sc.FIELD);                                           \
+        uint32_t *dst_ = reinterpret_cast<uint32_t *>(p);                                                              \
+        for (uint32_t i_ = threadIdx.x; i_ < words_; i_ += blockDim.x) dst_[i_] = src_[i_];                            \
+        v.FIELD = reinterpret_cast<const TYPE *>(p);                                                                   \
+        p += (words_ * 4u + 15u) & ~15u;                                                                               \
+    } while (0)
+        RT_STAGE(objects, DevObject, sc.n_objects);
+        RT_STAGE(leaves, DevLeaf, sc.n_leaves);
+        RT_STAGE(meshes, DevMesh, sc.n_meshes);
+        RT_STAGE(materials, DevMaterial, sc.n_materials);
+        RT_STAGE(textures, DevTexture, sc.n_textures);
+#undef RT_STAGE
+    }
+    __syncthreads();
+    return v;
+}
+
+// ------------------------------------------------------------------ ray generation
+// get_stratified_ray + Camera::pixel_ray (system.rs:237-242, 57-66) for slot `slot` of the shard;
+// false for the padding slots beyond the image edge
+RT_DEV bool primary_ray(const DevScene &sc, const RayQueue &q, const PassParams &pp, uint32_t slot, d3 &origin, d3 &dir,
+                        uint32_t &pixel)
+{
+    uint32_t x = 0, y = 0;
+    if (!rt_shard_decode(&q.g, q.rank, slot, &x, &y)) return false;
+    pixel = y * q.g.width + x;
+    rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, 0u, RT_RNG_SITE_JITTER, 0u);
+    double sx = (((double)q.s_i + rt_rng_u0(&blk)) * q.recip_sqrt_spp) - 0.5;
+    double sy = (((double)q.s_j + rt_rng_u1(&blk)) * q.recip_sqrt_spp) - 0.5;
+    double px = (double)x + sx, py = (double)y + sy;
+    double w = (double)q.g.width, h = (double)q.g.height;
+    double aspect = w / h;
+    double ndcx = px / w, ndcy = py / h;
+    double cx = (2.0 * ndcx - 1.0) * sc.cam_fov_factor * aspect;
+    double cy = (1.0 - 2.0 * ndcy) * sc.cam_fov_factor;
+    const double *m = sc.cam_c2w;
+    origin = mk3(m[12], m[13], m[14]);
+    d3 dp = mk3(cx * m[0] + cy * m[4] + -1.0 * m[8] + m[12], cx * m[1] + cy * m[5] + -1.0 * m[9] + m[13],
+                cx * m[2] + cy * m[6] + -1.0 * m[10] + m[14]);
+    dir = normalize3(dp - origin);
+    return true;
+}
+
+// origin, direction and random-number key of queue entry i; false for a padding slot
+RT_DEV bool fetch_ray(const DevScene &sc, const RayQueue &q, const PassParams &pp, uint32_t i, d3 &o, d3 &d, uint32_t &pixel)
+{
+    if (q.primary) return primary_ray(sc, q, pp, i, o, d, pixel);
+    o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+    d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+    pixel = q.pixel[i];
+    return true;
+}
+
+// index of the ray's pixel in the output buffers
+RT_DEV uint32_t ray_slot(const RayQueue &q, uint32_t i)
+{
+    if (!q.primary) return q.slot[i];
+    if (!q.row_major) return i;
+    uint32_t x = 0, y = 0;
+    (void)rt_shard_decode(&q.g, q.rank, i, &x, &y);
+    return y * q.g.width + x;
+}
+
+#define RT_HIT_PADDING (-2) // hit.obj of a padding slot: no ray, nothing to shade

@@ -1,0 +1,284 @@
+// rt_k_intersect.h — k_intersect: nearest hit over every object except the triangle work
+// (device code of librt_amd.so; included by rt_kernels.hip, which holds the host side of the C ABI)
+#pragma once
+
+#include "rt_k_common.h"
+
+// ------------------------------------------------------------------ nearest hit
+struct Candidate {
+    double t;
+    uint32_t aux;
+    bool ok;
+};
+
+// first_positive_intersection / first_intersection (shapes/mod.rs:45-55) over a list
+RT_DEV Candidate pick_from_list(const IvList &l, int mode)
+{
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    if (l.n == 0) return c;
+    if (mode == DM_FIRST_ENTRY) {
+        c.t = l.t[0];
+        c.aux = l.tag[0];
+        c.ok = true;
+        return c;
+    }
+    for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
+        if (i >= 2 * l.n) break;
+        if (!(l.t[i] < 0.0)) {
+            c.t = l.t[i];
+            c.aux = l.tag[i];
+            c.ok = true;
+            return c;
+        }
+    }
+    return c;
+}
+
+template <bool TORUS>
+RT_DEV Candidate eval_leaf_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
+{
+    const DevLeaf &L = sc.leaves[ob.leaf0];
+    LeafRay ry = to_leaf(L, o, d);
+    double t[4];
+    uint32_t sub[4];
+    int n = leaf_ends<TORUS>(L, ry, t, sub, gd);
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    int k = -1;
+    if (n > 0) {
+        if (ob.mode == DM_FIRST_ENTRY) {
+            k = 0;
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                if (i >= n) break;
+                if (!(t[i] < 0.0)) {
+                    k = i;
+                    break;
+                }
+            }
+        }
+    }
+    if (k >= 0) {
+        double tk = k == 0 ? t[0] : (k == 1 ? t[1] : (k == 2 ? t[2] : t[3]));
+        uint32_t sk = k == 0 ? sub[0] : (k == 1 ? sub[1] : (k == 2 ? sub[2] : sub[3]));
+        c.t = leaf_t_to_world(L, o, ry, tk);
+        c.aux = sk;
+        c.ok = true;
+    }
+    return c;
+}
+
+__device__ __noinline__ Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
+{
+    IvList res;
+    res.n = 0;
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    if (!csg_eval(sc, ob, o, d, res, gd)) return c;
+    return pick_from_list(res, ob.mode);
+}
+
+// Does the ray need the walk through a mesh of this object?  It must pass the Mesh::new box
+// (mesh.rs:32-42,117: no box hit, no intersection) and enter the triangles' own bounds before
+// the nearest hit found among the other objects (`have_hit`, `best_t`; slack keeps ties in play).
+RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 d, bool have_hit, double best_t)
+{
+    const DevLeaf &F = sc.leaves[ob.frame];
+    LeafRay ry = to_leaf(F, o, d);
+    d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
+    // object-space length per unit of world length (d need not have unit length: rt_trace_rays)
+    const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d)) / len3(d);
+    const double bound = have_hit ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
+    bool any = false;
+    for (int mi = 0; mi < ob.n_meshes; ++mi) {
+        const DevMesh &m = sc.meshes[ob.mesh0 + mi];
+        double t0, t1;
+        any = any || (mesh_box_hit(m, ry.o, inv) && mesh_clip(m, ry.o, inv, t0, t1) && t0 <= bound);
+    }
+    return any;
+}
+
+// HomogenousMedium::intersect (homogenous_medium.rs:29-57)
+template <bool CSG, bool TORUS>
+__device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
+                                                     d3 d, const PassParams &pp, uint32_t pixel, Guards &gd)
+{
+    Candidate c;
+    c.ok = false;
+    c.t = 0.0;
+    c.aux = 0u;
+    const DevLeaf &F = sc.leaves[ob.frame];
+    LeafRay ry = to_leaf(F, o, d);
+    // a world-space distance along the ray is `scale` times longer in the medium's space
+    double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d));
+    IvList res;
+    res.n = 0;
+    if (ob.prog_len == 0) {
+        leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
+    } else if (!CSG || !csg_eval(sc, ob, o, d, res, gd)) {
+        return c;
+    }
+    if (res.n == 0) return c;
+    int first = 0;
+    while (first < res.n && res.t[2 * first] < 0.0 && res.t[2 * first + 1] < 0.0) ++first; // skip_negative_intervals
+    double dlen = len3(ry.d);
+    uint32_t k = 0;
+    for (int i = first; i < res.n; ++i) {
+        double at = fmax(res.t[2 * i] * scale, 0.0), bt = res.t[2 * i + 1] * scale;
+        double distance = len3(ry.d * (bt - at));
+        rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_MEDIUM + k, obj_index);
+        ++k;
+        double hit_distance = -(1.0 / ob.density) * log(rt_rng_u0(&blk));
+        if (hit_distance < distance) {
+            double tm = at + hit_distance / dlen;
+            c.t = leaf_t_to_world(F, o, ry, tm);
+            c.ok = true;
+            return c;
+        }
+    }
+    return c;
+}
+
+// Pass 1 of the nearest-hit search: every object except the triangle work.
+// A ray that passes the bounding box of a mesh object is appended to
+// `mesh_queue`; k_mesh then walks the mesh grids and merges its result into the
+// hit record.  CSG / MEDIUM prune code (and registers) the
+// scene does not need.
+struct HitRec {
+    double t; // -1: nothing hit
+    d3 n;
+    double u, v;
+    int obj;
+};
+
+// Ray::trace (system.rs:122-133) over every object except the triangle work; returns whether
+// the ray still has to visit a mesh.
+template <bool CSG, bool MEDIUM, bool TORUS>
+RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, const PassParams &pp, HitRec &h, Guards &gd)
+{
+    bool wants_mesh = false;
+    // first object wins ties, t must be < f64::MAX
+    double best_t = DBL_MAX;
+    int best_obj = -1;
+    uint32_t best_aux = 0u;
+    const d3 inv_w = (CSG || MEDIUM || TORUS) ? mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z) : mk3(0, 0, 0);
+    for (int k = 0; k < sc.n_objects; ++k) {
+        const DevObject &ob = sc.objects[k];
+        Candidate c;
+        c.ok = false;
+        c.t = 0.0;
+        c.aux = 0u;
+        if ((CSG || MEDIUM || TORUS) && ob.has_bounds) {
+            // the expensive objects (CSG programs, fog boundaries, tori) carry the world bounds of all
+            // their leaves: a ray that misses those, or has them behind it, meets no leaf at t >= 0
+            double t0 = 0.0, t1 = 1.0e300; // NaNs (0 * inf) drop out of fmin / fmax: the box then counts as met
+            const double ax = (ob.wmin[0] - o.x) * inv_w.x, bx = (ob.wmax[0] - o.x) * inv_w.x;
+            t0 = fmax(t0, fmin(ax, bx));
+            t1 = fmin(t1, fmax(ax, bx));
+            const double ay = (ob.wmin[1] - o.y) * inv_w.y, by = (ob.wmax[1] - o.y) * inv_w.y;
+            t0 = fmax(t0, fmin(ay, by));
+            t1 = fmin(t1, fmax(ay, by));
+            const double az = (ob.wmin[2] - o.z) * inv_w.z, bz = (ob.wmax[2] - o.z) * inv_w.z;
+            t0 = fmax(t0, fmin(az, bz));
+            t1 = fmin(t1, fmax(az, bz));
+            if (t0 > t1 + 1e-9 * (fabs(t1) + 1.0)) continue;
+        }
+        switch (ob.kind) {
+        case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
+        case DO_CSG:
+            if (CSG) c = eval_csg_object(sc, ob, o, d, gd);
+            break;
+        case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
+        default:
+            if (MEDIUM) c = eval_medium_object<CSG, TORUS>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
+            break;
+        }
+        // Object::intersect keeps t >= 0 (object.rs:50-54)
+        if (c.ok && c.t >= 0.0 && c.t < DBL_MAX && (best_obj < 0 || c.t < best_t)) {
+            best_t = c.t;
+            best_obj = k;
+            best_aux = c.aux;
+        }
+    }
+
+    if (wants_mesh) {
+        wants_mesh = false;
+        for (int k = 0; k < sc.n_objects; ++k) {
+            const DevObject &ob = sc.objects[k];
+            if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, d, best_obj >= 0, best_t);
+        }
+    }
+
+    d3 n = mk3(0.0, 0.0, 0.0);
+    double u = 0.0, v = 0.0;
+    if (best_obj >= 0) {
+        const DevObject &ob = sc.objects[best_obj];
+        const bool need_uv = ob.needs_uv || pp.force_uv;
+        d3 pw = o + d * best_t;
+        if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
+            const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
+            LeafRay ry = to_leaf(L, o, d);
+            d3 ql = L.identity ? pw : xf_point(L.W, pw);
+            d3 nl;
+            leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
+            n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
+            if (best_aux & TAG_NEG) n = -n;
+        } else {
+            const DevLeaf &F = sc.leaves[ob.frame];
+            n = F.identity ? mk3(1.0, 0.0, 0.0) : normalize3(xf_normal(F.W, mk3(1.0, 0.0, 0.0)));
+        }
+    }
+    h.t = best_obj >= 0 ? best_t : -1.0;
+    h.n = n;
+    h.u = u;
+    h.v = v;
+    h.obj = best_obj;
+    return wants_mesh;
+}
+
+template <bool CSG, bool MEDIUM, bool TORUS>
+__global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
+                                                         PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
+                                                         uint32_t *mesh_queue, uint32_t *mesh_count)
+{
+    extern __shared__ double4 scene_lds[];
+    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    __shared__ uint32_t append_lds[RT_BLOCK / 64 + 1];
+    const uint32_t count = *count_ptr;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    Guards gd;
+    for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
+    gd.overflow = 0u;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        bool wants_mesh = false;
+        d3 o, d;
+        uint32_t pixel = 0u;
+        if (i < count && !fetch_ray(sc, q, pp, i, o, d, pixel)) {
+            hit.obj[i] = RT_HIT_PADDING;
+        } else if (i < count) {
+            HitRec h;
+            wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
+            hit.t[i] = h.t;
+            hit.n[0][i] = h.n.x;
+            hit.n[1][i] = h.n.y;
+            hit.n[2][i] = h.n.z;
+            hit.uv[0][i] = h.u;
+            hit.uv[1][i] = h.v;
+            hit.obj[i] = h.obj;
+            if (primary_ids) primary_ids[ray_slot(q, i)] = h.obj;
+        }
+        uint32_t at = block_append(wants_mesh, mesh_count, append_lds);
+        if (wants_mesh) mesh_queue[at] = i;
+    }
+    for (int k = 0; k < 5; ++k)
+        if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
+    if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
+}

@@ -1,0 +1,343 @@
+// rt_k_shade.h — k_shade, k_tail and the small frame-buffer kernels
+// (device code of librt_amd.so; included by rt_kernels.hip, which holds the host side of the C ABI)
+#pragma once
+
+#include "rt_k_intersect.h"
+#include "rt_k_mesh.h"
+
+// ------------------------------------------------------------------ shading
+// direction.rs:29-39
+RT_DEV d3 uniform_sphere(const PassParams &pp, uint32_t pixel)
+{
+    rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_SPHERE, 0u);
+    double theta = 2.0 * RT_PI * rt_rng_u0(&blk);
+    double phi = acos(1.0 - 2.0 * rt_rng_u1(&blk));
+    double sp, cp, st, ct;
+    sincos(phi, &sp, &cp);
+    sincos(theta, &st, &ct);
+    return mk3(sp * ct, sp * st, cp);
+}
+
+RT_DEV uint32_t sat_u32(double v)
+{
+    if (!(v > 0.0)) return 0u;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+
+// texture.rs:54-94
+RT_DEV d3 texture_color(const DevScene &sc, int tex, double u, double v)
+{
+    const DevTexture &t = sc.textures[tex];
+    if (t.kind == RT_TEX_SOLID) return mk3(t.c1[0], t.c1[1], t.c1[2]);
+    if (t.kind == RT_TEX_CHECKERBOARD) {
+        double sx = u * t.scale, sy = v * t.scale;
+        double fx = sx - trunc(sx), fy = sy - trunc(sy);
+        bool xp = (fabs(fx) > 0.5) != (fx < 0.0);
+        bool yp = (fabs(fy) > 0.5) != (fy < 0.0);
+        double p = (xp != yp) ? 1.0 : 0.0;
+        return mk3(t.c1[0], t.c1[1], t.c1[2]) * (1.0 - p) + mk3(t.c2[0], t.c2[1], t.c2[2]) * p;
+    }
+    double max_x = (double)(t.width - 1), max_y = (double)(t.height - 1);
+    uint32_t x = sat_u32(u * t.scale * max_x) % (uint32_t)t.width;
+    uint32_t y = sat_u32(v * t.scale * max_y) % (uint32_t)t.height;
+    const uint8_t *c = sc.image_data + t.offset + ((size_t)y * (size_t)t.width + x) * 3;
+    return mk3((double)c[0] / 255.0, (double)c[1] / 255.0, (double)c[2] / 255.0);
+}
+
+RT_DEV double clampd(double lo, double hi, double v) { return fmax(lo, fmin(hi, v)); }
+
+// dielectric.rs:89-108
+RT_DEV double fresnel(d3 inc, d3 nrm, double ior)
+{
+    double cos_i = clampd(-1.0, 1.0, dot3(inc, nrm));
+    double eta_i = 1.0, eta_t = ior;
+    if (cos_i > 0.0) {
+        eta_i = ior;
+        eta_t = 1.0;
+    }
+    double sin_t = eta_i / eta_t * sqrt(fmax(1.0 - cos_i * cos_i, 0.0));
+    if (sin_t >= 1.0) return 1.0;
+    double cos_t = sqrt(fmax(1.0 - sin_t * sin_t, 0.0));
+    cos_i = fabs(cos_i);
+    double r_s = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    double r_p = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_s * r_s + r_p * r_p) / 2.0;
+}
+
+// dielectric.rs:68-86
+RT_DEV d3 refract(d3 inc, d3 nrm, double ior)
+{
+    double cos_i = clampd(-1.0, 1.0, dot3(inc, nrm));
+    double eta_i = 1.0, eta_t = ior;
+    d3 n = nrm;
+    if (cos_i < 0.0) {
+        cos_i = -cos_i;
+    } else {
+        eta_i = ior;
+        eta_t = 1.0;
+        n = -nrm;
+    }
+    double eta = eta_i / eta_t;
+    double k = 1.0 - eta * eta * (1.0 - cos_i * cos_i);
+    if (k < 0.0) return mk3(0.0, 0.0, 0.0);
+    return inc * eta + n * (eta * cos_i - sqrt(k));
+}
+
+RT_DEV d3 reflect3(d3 d, d3 n) { return d - (n * 2.0) * dot3(d, n); } // direction.rs:75-77
+
+// One path segment's end (system.rs:112-120,135-142): either the path goes on (returns true; `o`,
+// `d`, `thr` become the scattered ray and the updated attenuation) or it ends seeing `X`.
+RT_DEV bool shade_one(const DevScene &sc, d3 &o, d3 &d, d3 &thr, uint32_t pixel, const HitRec &h, const PassParams &pp,
+                      d3 bg, d3 &X)
+{
+    X = bg; // what the path sees where it ends
+    if (h.obj < 0) return false;
+    const d3 n = h.n;
+    const double u = h.u, v = h.v;
+    const DevMaterial &m = sc.materials[sc.objects[h.obj].material];
+    d3 p = o + d * h.t; // RayHit::point (system.rs:173-175)
+    d3 att = mk3(1.0, 1.0, 1.0);
+    d3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
+    switch (m.kind) {
+    case RT_MAT_LAMBERTIAN: {
+        // lambertian.rs:20-31
+        no = p + n * pp.bias;
+        d3 target = p + n + uniform_sphere(pp, pixel);
+        nd = normalize3(target - p);
+        att = texture_color(sc, m.texture, u, v);
+        break;
+    }
+    case RT_MAT_METAL: {
+        // metal.rs:21-32
+        d3 refl = normalize3(reflect3(d, n));
+        d3 fz = m.fuzz * uniform_sphere(pp, pixel);
+        no = p + n * pp.bias;
+        nd = normalize3(refl + fz);
+        att = texture_color(sc, m.texture, u, v);
+        break;
+    }
+    case RT_MAT_DIELECTRIC: {
+        // dielectric.rs:25-53
+        bool outside = dot3(d, n) < 0.0;
+        d3 b = n * pp.bias;
+        double kr = fresnel(d, n, m.ior);
+        rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_DIELECTRIC, 0u);
+        d3 fz = m.fuzz * uniform_sphere(pp, pixel);
+        if (rt_rng_u0(&blk) < kr) {
+            nd = normalize3(reflect3(d, n) + fz);
+            no = outside ? p + b : p - b;
+        } else {
+            nd = normalize3(refract(d, n, m.ior) + fz);
+            no = outside ? p - b : p + b;
+        }
+        break;
+    }
+    case RT_MAT_DIFFUSE_LIGHT: {
+        // diffuse_light.rs:19-26 + system.rs:139: emit + background
+        X = m.intensity * texture_color(sc, m.texture, u, v) + bg;
+        return false;
+    }
+    default: {
+        // isotropic.rs:19-26
+        no = p;
+        nd = uniform_sphere(pp, pixel);
+        att = texture_color(sc, m.texture, u, v);
+        break;
+    }
+    }
+    thr = mk3(thr.x * att.x, thr.y * att.y, thr.z * att.z);
+    o = no;
+    d = nd;
+    // the scattered ray has depth + 1; Ray::cast returns the background at max_depth
+    return pp.depth + 1u < pp.max_depth;
+}
+
+__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
+                                                     RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
+{
+    extern __shared__ double4 scene_lds[];
+    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
+    const uint32_t count = *count_in_ptr;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), thr = mk3(0, 0, 0);
+        uint32_t slot = 0, pixel = 0;
+        HitRec h;
+        h.obj = i < count ? hit.obj[i] : RT_HIT_PADDING;
+        if (h.obj != RT_HIT_PADDING) {
+            h.t = 0.0;
+            h.n = mk3(0, 0, 0);
+            h.u = h.v = 0.0;
+            if (qin.primary) {
+                thr = mk3(1.0, 1.0, 1.0);
+                (void)primary_ray(sc, qin, pp, i, o, d, pixel);
+                slot = qin.row_major ? pixel : i;
+            } else {
+                slot = qin.slot[i];
+                pixel = qin.pixel[i];
+                thr = mk3(qin.thr[0][i], qin.thr[1][i], qin.thr[2][i]);
+                if (h.obj >= 0) {
+                    o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
+                    d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
+                }
+            }
+            if (h.obj >= 0) {
+                h.t = hit.t[i];
+                h.n = mk3(hit.n[0][i], hit.n[1][i], hit.n[2][i]);
+                h.u = hit.uv[0][i];
+                h.v = hit.uv[1][i];
+            }
+            d3 X;
+            alive = shade_one(sc, o, d, thr, pixel, h, pp, bg, X);
+            if (!alive) {
+                double *px = fb + (size_t)slot * 3;
+                px[0] += thr.x * X.x;
+                px[1] += thr.y * X.y;
+                px[2] += thr.z * X.z;
+            }
+        }
+        uint32_t at = block_append(alive, count_out, append_lds);
+        if (alive) {
+            qout.o[0][at] = o.x;
+            qout.o[1][at] = o.y;
+            qout.o[2][at] = o.z;
+            qout.d[0][at] = d.x;
+            qout.d[1][at] = d.y;
+            qout.d[2][at] = d.z;
+            qout.thr[0][at] = thr.x;
+            qout.thr[1][at] = thr.y;
+            qout.thr[2][at] = thr.z;
+            qout.slot[at] = slot;
+            qout.pixel[at] = pixel;
+        }
+    }
+}
+
+// The tail of a stratum: once few paths are left, one wave takes one path through all of its
+// remaining segments - nearest hit over the analytic objects (every lane computes the same),
+// the meshes by brute force across the 64 lanes, the material - with no launch per bounce.
+// The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
+// as separate launches.  counts[k] gains one for every ray traced at depth k.
+template <bool CSG, bool MEDIUM, bool TORUS>
+__global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
+                                                    double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
+                                                    uint32_t *lane_totals)
+{
+    extern __shared__ double4 scene_lds[];
+    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    const uint32_t count = counts[pp.depth];
+    // a scene with meshes: one wave per path (the 64 lanes share the mesh test); without: one lane per path
+    const bool per_lane = !has_mesh;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
+    const uint32_t unit = per_lane ? tid : tid >> 6, n_units = per_lane ? n_threads : n_threads >> 6;
+    const bool writer = per_lane || lane_id() == 0u;
+    const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+    Guards gd;
+    for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
+    gd.overflow = 0u;
+    uint32_t my_rays = 0u, my_depth = 0u; // per_lane: segments traced beyond the first, deepest level reached
+    for (uint32_t i = unit; i < count; i += n_units) {
+        d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+        d3 thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
+        const uint32_t slot = q.slot[i], pixel = q.pixel[i];
+        PassParams p = pp;
+        for (;;) {
+            HitRec h;
+            bool wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, p, h, gd);
+            if (has_mesh && wants_mesh) {
+                int best_obj = h.obj;
+                double best_t = best_obj >= 0 ? h.t : DBL_MAX;
+                uint32_t best_aux = 0u;
+                if (mesh_brute_wave(sc, o, d, best_obj, best_t, best_aux)) {
+                    h.t = best_t;
+                    h.obj = best_obj;
+                    mesh_hit_surface(sc, o, d, best_obj, best_aux, h.n, h.u, h.v);
+                }
+            }
+            d3 X;
+            const bool alive = shade_one(sc, o, d, thr, pixel, h, p, bg, X);
+            if (!alive) {
+                if (writer) {
+                    double *px = fb + (size_t)slot * 3;
+                    px[0] += thr.x * X.x;
+                    px[1] += thr.y * X.y;
+                    px[2] += thr.z * X.z;
+                }
+                break;
+            }
+            ++p.depth;
+            // rays per depth level: one atomic per segment is fine for a wave per path; lanes
+            // would hammer a few words, so they keep a total and the deepest level instead
+            if (per_lane) {
+                ++my_rays;
+                my_depth = p.depth > my_depth ? p.depth : my_depth;
+            } else if (writer) {
+                atomicAdd(&counts_out[p.depth], 1u);
+            }
+        }
+    }
+    if (per_lane) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            my_rays += __shfl_xor(my_rays, off);
+            const uint32_t od = __shfl_xor(my_depth, off);
+            my_depth = od > my_depth ? od : my_depth;
+            for (int k = 0; k < 5; ++k) gd.g[k] += __shfl_xor(gd.g[k], off);
+            gd.overflow += __shfl_xor(gd.overflow, off);
+        }
+        if (lane_id() == 0u) {
+            if (my_rays) atomicAdd(&lane_totals[0], my_rays);
+            if (my_depth) atomicMax(&lane_totals[1], my_depth);
+        }
+    }
+    if (lane_id() == 0u) { // wave per path: every lane counted the same events; lane per path: summed above
+        for (int k = 0; k < 5; ++k)
+            if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
+        if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
+    }
+}
+
+// max_depth == 0: every primary ray returns the background (system.rs:113-114)
+__global__ void k_fill_background(DevScene sc, rt_shard_geom g, uint32_t rank, uint32_t n_slots, double *fb, int row_major)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x, y;
+    if (slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y)) {
+        if (row_major) slot = y * g.width + x;
+        fb[(size_t)slot * 3 + 0] += sc.background[0];
+        fb[(size_t)slot * 3 + 1] += sc.background[1];
+        fb[(size_t)slot * 3 + 2] += sc.background[2];
+    }
+}
+
+__global__ void k_unshard(rt_shard_geom g, uint32_t rank, uint32_t n_slots, const double *shard_rgb, double *full_rgb,
+                          const int32_t *shard_ids, int32_t *full_ids)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x, y;
+    if (slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y)) {
+        size_t p = (size_t)y * g.width + x;
+        if (shard_rgb && full_rgb) {
+            full_rgb[p * 3 + 0] = shard_rgb[(size_t)slot * 3 + 0];
+            full_rgb[p * 3 + 1] = shard_rgb[(size_t)slot * 3 + 1];
+            full_rgb[p * 3 + 2] = shard_rgb[(size_t)slot * 3 + 2];
+        }
+        if (shard_ids && full_ids) full_ids[p] = shard_ids[slot];
+    }
+}
+
+__global__ void k_iota(uint32_t n, uint32_t *slot, uint32_t *pixel, double *t0, double *t1, double *t2)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        slot[i] = i;
+        pixel[i] = i;
+        t0[i] = t1[i] = t2[i] = 1.0;
+    }
+}
