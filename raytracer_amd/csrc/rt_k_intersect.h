@@ -228,7 +228,9 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
             d3 ql = L.identity ? pw : xf_point(L.W, pw);
             d3 nl;
             leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
-            n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
+            // system.rs:196 normalises every world normal; only a plane's own normal can arrive
+            // un-normalised (`normal <0, 2, 0>`), every other shape hands over a unit vector
+            n = L.identity ? (L.kind == DL_PLANE ? normalize3(nl) : nl) : normalize3(xf_normal(L.W, nl));
             if (best_aux & TAG_NEG) n = -n;
         } else {
             const DevLeaf &F = sc.leaves[ob.frame];

@@ -1,6 +1,8 @@
 """Build small rt_scene_desc values from Python for unit-level tests."""
 import ctypes as C
 
+import numpy as np
+
 from raytracer_amd import _capi
 
 IDENT = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0]
@@ -13,7 +15,8 @@ class Desc:
     """Keeps the ctypes arrays alive next to the rt_scene_desc that points at them."""
 
     def __init__(self, shapes):
-        """shapes: list of {"kind", "params", optional "flags"}; one white lambertian object per shape."""
+        """shapes: list of {"kind", "params", optional "flags", optional "o2w" (16 doubles, row-major,
+        row-vector convention; its inverse becomes w2o)}; one white lambertian object per shape."""
         n = len(shapes)
         self.nodes = (_capi.rt_shape_node * n)()
         self.objects = (_capi.rt_object * n)()
@@ -24,9 +27,15 @@ class Desc:
             nd.flags = s.get("flags", 0)
             for k, v in enumerate(s["params"]):
                 nd.params[k] = float(v)
+            o2w = s.get("o2w", IDENT)
+            w2o = IDENT
+            if "o2w" in s:
+                inv = np.linalg.inv(np.array(o2w, dtype=float).reshape(4, 4))
+                inv[:, 3] = [0.0, 0.0, 0.0, 1.0]          # affine: the last column is exact
+                w2o = inv.reshape(16).tolist()
             for k in range(16):
-                nd.o2w[k] = IDENT[k]
-                nd.w2o[k] = IDENT[k]
+                nd.o2w[k] = float(o2w[k])
+                nd.w2o[k] = float(w2o[k])
             self.objects[i].shape = i
             self.objects[i].material = 0
         self.materials = (_capi.rt_material * 1)()

@@ -381,6 +381,53 @@ def test_ray_batches_several_meshes(rt, n_rays):
         dev.trace_rays(ro[:4], rd[:4] * 2.0, seed=4)
 
 
+def _random_affine(rng):
+    """rotation * non-uniform scale, then a translation; row-vector convention (point * M)."""
+    a, b, c = rng.uniform(0, 2 * np.pi, 3)
+    rx = np.array([[1, 0, 0], [0, np.cos(a), np.sin(a)], [0, -np.sin(a), np.cos(a)]])
+    ry = np.array([[np.cos(b), 0, -np.sin(b)], [0, 1, 0], [np.sin(b), 0, np.cos(b)]])
+    rz = np.array([[np.cos(c), np.sin(c), 0], [-np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    m = np.eye(4)
+    m[:3, :3] = np.diag(rng.uniform(0.5, 1.8, 3)) @ rx @ ry @ rz
+    m[3, :3] = rng.uniform(-2.5, 2.5, 3)
+    return m.reshape(16).tolist()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_transformed_primitives(rt, seed):
+    """Fuzz: every primitive kind under random rotations, non-uniform scales and translations (the composed
+    world->leaf / leaf->world maps, `Intersection::to_world`'s t and normal), 24 objects, 60 000 rays."""
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for i in range(24):
+        kind = ["sphere", "cube", "cylinder", "torus", "xyrect", "xzrect", "zyrect", "plane"][i % 8]
+        params = {"sphere": [*rng.uniform(-0.5, 0.5, 3), rng.uniform(0.3, 0.9)],
+                  "cube": [*rng.uniform(-0.8, -0.2, 3), *rng.uniform(0.2, 0.8, 3)],
+                  "cylinder": [rng.uniform(0.3, 0.8), rng.uniform(0.5, 1.5)],
+                  "torus": [rng.uniform(0.6, 1.0), rng.uniform(0.1, 0.3)],
+                  "xyrect": [*rng.uniform(-0.3, 0.3, 3), rng.uniform(0.5, 2), rng.uniform(0.5, 2)],
+                  "xzrect": [*rng.uniform(-0.3, 0.3, 3), rng.uniform(0.5, 2), rng.uniform(0.5, 2)],
+                  "zyrect": [*rng.uniform(-0.3, 0.3, 3), rng.uniform(0.5, 2), rng.uniform(0.5, 2)],
+                  "plane": [0, -4.0 - i, 0, *rng.normal(size=3)]}[kind]
+        shape = {"kind": kind, "params": params}
+        if kind != "plane" and i >= 8:                      # the first of each kind stays untransformed
+            shape["o2w"] = _random_affine(rng)
+        shapes.append(shape)
+    d = descs.Desc(shapes)
+    dev = rt.DeviceScene(descs.FakeScene(d))
+    ro, rd = _random_rays(60000, 100 + seed, np.array([0.0, 0.0, 0.0]), 3.5)
+    got, gst = dev.trace_rays(ro, rd, seed=4)
+    ref, rst = oracle_lib.trace_rays(d.ptr, ro, rd, seed=4)
+    assert (ref["object"] >= 0).mean() > 0.5 and len(np.unique(ref["object"])) >= 20
+    same = got["object"] == ref["object"]
+    assert same.mean() >= ID_MATCH_MIN, same.mean()
+    hit = same & (ref["object"] >= 0)
+    scale = np.maximum(1.0, np.abs(ref["t"][hit]))
+    assert np.mean(np.abs(got["t"][hit] - ref["t"][hit]) / scale < 1e-8) >= ID_MATCH_MIN
+    assert np.mean(np.all(np.abs(got["n"][hit] - ref["n"][hit]) < 1e-6, axis=1)) >= ID_MATCH_MIN
+    assert list(gst.guards) == list(rst.guards)
+
+
 def test_reference_known_answers_on_device(rt):
     """The reference's own unit-test vectors, first hit through rt_trace_rays."""
     for case in GOLD["shape_intervals"]:
