@@ -484,6 +484,20 @@ RT_DEV bool iv_sort(IvList &l)
 __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B, IvList &out, Guards &gd)
 {
     out.n = 0;
+    // The number of intervals written lives in a register (`n_out`) and reaches out.n once, at the end.
+    int n_out = 0;
+#define PUSH(T0, G0, T1, G1)                                                                                           \
+    do {                                                                                                               \
+        if (n_out >= DEV_MAX_INTERVALS) {                                                                              \
+            gd.overflow++;                                                                                             \
+        } else {                                                                                                       \
+            out.t[2 * n_out] = (T0);                                                                                   \
+            out.tag[2 * n_out] = (G0);                                                                                 \
+            out.t[2 * n_out + 1] = (T1);                                                                               \
+            out.tag[2 * n_out + 1] = (G1);                                                                             \
+            ++n_out;                                                                                                   \
+        }                                                                                                              \
+    } while (0)
     if (op == DEV_OP_UNION) {
         if (A.n == 0) {
             iv_copy(out, B);
@@ -502,41 +516,40 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
             return true;
         }
     }
-    int pa = 1, pb = 1;
-    bool ha = true, hb = true;
+    // ia / ib: index of the interval currently held in (as, ae) / (bs, be); "Some" while the index is inside
+    // its list.  (Integer indices rather than boolean flags carried round the loop.)
+    int ia = 0, ib = 0;
     double as = A.t[0], ae = A.t[1], bs = B.t[0], be = B.t[1];
     uint32_t asg = A.tag[0], aeg = A.tag[1], bsg = B.tag[0], beg = B.tag[1];
 #define NEXT_A()                                                                                                       \
     do {                                                                                                               \
-        if (pa < A.n) {                                                                                                \
-            as = A.t[2 * pa];                                                                                          \
-            ae = A.t[2 * pa + 1];                                                                                      \
-            asg = A.tag[2 * pa];                                                                                       \
-            aeg = A.tag[2 * pa + 1];                                                                                   \
-            ++pa;                                                                                                      \
-        } else                                                                                                         \
-            ha = false;                                                                                                \
+        ++ia;                                                                                                          \
+        if (ia < A.n) {                                                                                                \
+            as = A.t[2 * ia];                                                                                          \
+            ae = A.t[2 * ia + 1];                                                                                      \
+            asg = A.tag[2 * ia];                                                                                       \
+            aeg = A.tag[2 * ia + 1];                                                                                   \
+        }                                                                                                              \
     } while (0)
 #define NEXT_B()                                                                                                       \
     do {                                                                                                               \
-        if (pb < B.n) {                                                                                                \
-            bs = B.t[2 * pb];                                                                                          \
-            be = B.t[2 * pb + 1];                                                                                      \
-            bsg = B.tag[2 * pb];                                                                                       \
-            beg = B.tag[2 * pb + 1];                                                                                   \
-            ++pb;                                                                                                      \
-        } else                                                                                                         \
-            hb = false;                                                                                                \
+        ++ib;                                                                                                          \
+        if (ib < B.n) {                                                                                                \
+            bs = B.t[2 * ib];                                                                                          \
+            be = B.t[2 * ib + 1];                                                                                      \
+            bsg = B.tag[2 * ib];                                                                                       \
+            beg = B.tag[2 * ib + 1];                                                                                   \
+        }                                                                                                              \
     } while (0)
     int guard_iter = 0;
-    while (ha && hb) {
+    while (ia < A.n && ib < B.n) {
         if (++guard_iter > 8 * DEV_MAX_INTERVALS) break; // cannot happen; keeps the loop provably finite
         if (op == DEV_OP_UNION) {
             if (ae < bs) {
-                iv_push(out, as, asg, ae, aeg, gd);
+                PUSH(as, asg, ae, aeg);
                 NEXT_A();
             } else if (be < as) {
-                iv_push(out, bs, bsg, be, beg, gd);
+                PUSH(bs, bsg, be, beg);
                 NEXT_B();
             } else {
                 double ns = as, ne = ae;
@@ -549,14 +562,14 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
                     ne = be;
                     neg = beg;
                     NEXT_A();
-                    while (ha) {
+                    while (ia < A.n) {
                         if (as > ne) break;
                         ne = ae;
                         neg = aeg;
                         NEXT_A();
                     }
                 }
-                iv_push(out, ns, nsg, ne, neg, gd);
+                PUSH(ns, nsg, ne, neg);
                 NEXT_B();
             }
         } else if (op == DEV_OP_INTERSECTION) {
@@ -566,7 +579,7 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
                 NEXT_B();
             } else {
                 bool s_from_a = as > bs, e_from_a = ae < be;
-                iv_push(out, s_from_a ? as : bs, s_from_a ? asg : bsg, e_from_a ? ae : be, e_from_a ? aeg : beg, gd);
+                PUSH(s_from_a ? as : bs, s_from_a ? asg : bsg, e_from_a ? ae : be, e_from_a ? aeg : beg);
                 if (be >= ae)
                     NEXT_A();
                 else
@@ -574,7 +587,7 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
             }
         } else {
             if (ae < bs) {
-                iv_push(out, as, asg, ae, aeg, gd);
+                PUSH(as, asg, ae, aeg);
                 NEXT_A();
             } else if (be < as) {
                 NEXT_B();
@@ -585,12 +598,12 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
                 asg = beg ^ TAG_NEG;
                 NEXT_B();
             } else if (bs < ae && be < ae) {
-                iv_push(out, as, asg, bs, bsg ^ TAG_NEG, gd);
+                PUSH(as, asg, bs, bsg ^ TAG_NEG);
                 as = be;
                 asg = beg ^ TAG_NEG;
                 NEXT_B();
             } else if (bs < ae && be >= ae) {
-                iv_push(out, as, asg, bs, bsg ^ TAG_NEG, gd);
+                PUSH(as, asg, bs, bsg ^ TAG_NEG);
                 NEXT_A();
             } else {
                 gd.g[2]++;
@@ -599,27 +612,21 @@ __device__ __noinline__ bool csg_apply(int op, const IvList &A, const IvList &B,
         }
     }
     if (op == DEV_OP_UNION) {
-        if (ha)
-            iv_push(out, as, asg, ae, aeg, gd);
-        else if (hb)
-            iv_push(out, bs, bsg, be, beg, gd);
-        while (pa < A.n) {
-            iv_push(out, A.t[2 * pa], A.tag[2 * pa], A.t[2 * pa + 1], A.tag[2 * pa + 1], gd);
-            ++pa;
-        }
-        while (pb < B.n) {
-            iv_push(out, B.t[2 * pb], B.tag[2 * pb], B.t[2 * pb + 1], B.tag[2 * pb + 1], gd);
-            ++pb;
-        }
+        // the interval in hand first (a's if there is one, else b's), then the untouched rest of both lists
+        if (ia < A.n)
+            PUSH(as, asg, ae, aeg);
+        else if (ib < B.n)
+            PUSH(bs, bsg, be, beg);
+        for (int k = ia + 1; k < A.n; ++k) PUSH(A.t[2 * k], A.tag[2 * k], A.t[2 * k + 1], A.tag[2 * k + 1]);
+        for (int k = ib + 1; k < B.n; ++k) PUSH(B.t[2 * k], B.tag[2 * k], B.t[2 * k + 1], B.tag[2 * k + 1]);
     } else if (op == DEV_OP_DIFFERENCE) {
-        if (ha) iv_push(out, as, asg, ae, aeg, gd);
-        while (pa < A.n) {
-            iv_push(out, A.t[2 * pa], A.tag[2 * pa], A.t[2 * pa + 1], A.tag[2 * pa + 1], gd);
-            ++pa;
-        }
+        if (ia < A.n) PUSH(as, asg, ae, aeg);
+        for (int k = ia + 1; k < A.n; ++k) PUSH(A.t[2 * k], A.tag[2 * k], A.t[2 * k + 1], A.tag[2 * k + 1]);
     }
 #undef NEXT_A
 #undef NEXT_B
+#undef PUSH
+    out.n = n_out;
     if (!iv_sort(out)) {
         gd.g[4]++;
         return false;

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import descs
+import fuzz_scenes
 import oracle_lib
 import parity
 
@@ -426,6 +427,61 @@ def test_random_transformed_primitives(rt, seed):
     assert np.mean(np.abs(got["t"][hit] - ref["t"][hit]) / scale < 1e-8) >= ID_MATCH_MIN
     assert np.mean(np.all(np.abs(got["n"][hit] - ref["n"][hit]) < 1e-6, axis=1)) >= ID_MATCH_MIN
     assert list(gst.guards) == list(rst.guards)
+
+
+@pytest.mark.parametrize("seed,torus", [(s, True) for s in range(1, 9)] + [(s, False) for s in range(60, 80)])
+def test_random_scenes(rt, seed, torus):
+    """Fuzz over the whole scene grammar (tests/fuzz_scenes.py): CSG trees with transforms at every level, meshes,
+    media, every material and texture.  Without tori every path must follow the oracle's (same ray count, every
+    pixel within 1e-9); with tori the quartic's libm differences may fork a path in 25 000."""
+    text = fuzz_scenes.scene_text(seed, torus=torus)
+    o = rt.Options(width=160, height=120, samples=4, seed=seed)
+    sc = rt.parse(o, text, parity.ASSETS)
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    m = parity.compare(rgb, ids, ref, rids, st.strata)
+    _check(m, st, rst)
+    if not torus:
+        assert st.rays == rst.rays and m["px_close"] == 1.0 and m["id_match"] == 1.0, (m, st.rays, rst.rays)
+
+
+def test_difference_of_a_two_interval_union(rt):
+    """Regression (found by the fuzz above, seeds 64 and 76 without tori): `difference { union { a b } c }` where
+    the ray meets a and b in two separate intervals, c swallows the first and trims the second.  The device lost
+    the trimmed interval: the loop that merges two interval lists carried two boolean flags round a loop with two
+    dozen exits and came out of the compiler wrong (numerics and parity notes); csg_apply now keeps
+    integer indices instead."""
+    text = """camera { origin <0.0467, 1.8314, 7.04> look_at <0.9663, 1.5929, 2.0043> fov 20 }
+object "x" { difference {
+    union { cube { <-0.5779, -0.3604, -0.5133> <0.1462, 1.1246, 0.9012>
+                   transform { rotate_x 170.207 translate <-0.0036, 0.6639, 0.1757> } }
+            sphere { origin <0.0321, -0.2402, 0.1231> radius 0.9806
+                     transform { rotate_y 114.9958 translate <0.3196, 0.5964, -0.339> } }
+            transform { translate <-0.107, 0.31, -0.2615> } }
+    cube { <-0.2696, -0.8113, -0.3193> <0.7057, -0.2483, 0.4454> transform { translate <-0.092, 0.3407, 0.0238> } }
+    transform { translate <0.9663, 1.5929, 2.0043> } }
+  material { lambertian texture { solid color white } } }
+"""
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse(o, text, parity.ASSETS)
+    # the ray that failed, and a cone of rays from the same eye point over the whole object
+    ro = np.tile(np.array([0.0467, 1.8314, 7.04]), (40001, 1))
+    rng = np.random.default_rng(7)
+    tgt = np.array([0.9663, 1.5929, 2.0043]) + rng.uniform(-1.6, 1.6, (40001, 3))
+    rd = tgt - ro
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd[0] = [0.18580452142331003, -0.07441346100994915, -0.9797649292759849]
+    rd[0] /= np.linalg.norm(rd[0])
+    dev = rt.DeviceScene(sc)
+    got, _ = dev.trace_rays(ro, rd, seed=4)
+    ref, _ = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    assert ref["object"][0] == 0 and abs(ref["t"][0] - 5.441305195461109) < 1e-9
+    assert got["object"][0] == 0 and abs(got["t"][0] - ref["t"][0]) < 1e-9
+    assert np.array_equal(got["object"], ref["object"])
+    hit = ref["object"] >= 0
+    assert 0.2 < hit.mean() < 0.95
+    assert np.max(np.abs(got["t"][hit] - ref["t"][hit])) < 1e-9
+    assert np.max(np.abs(got["n"][hit] - ref["n"][hit])) < 1e-9
 
 
 def test_reference_known_answers_on_device(rt):
