@@ -10,7 +10,9 @@
 #pragma once
 #include "rt_dev_math.h"
 
-// end-point tag: bits 0-7 leaf (object-relative), 8-10 part, 11 normal negated
+// end-point tag: bits 0-7 leaf (object-relative), 8-10 part, 11 normal negated,
+// 12-31 to_world steps the reference skipped on the way up (DEV_PROG_SKIP, one bit per skip_ord)
+#define TAG_SKIP_SHIFT 12
 #define TAG_PART_SHIFT 8
 #define TAG_NEG (1u << 11)
 #define PART_CYL_SIDE 0u
@@ -650,6 +652,15 @@ RT_DEV void leaf_world_intervals(const DevLeaf &L, uint32_t rel, d3 ow, d3 dw, I
     }
 }
 
+// DEV_PROG_SKIP: length of the ray direction in the node's space over its length in the parent's space
+RT_DEV double skip_scale(const DevLeaf &Q, d3 dw)
+{
+    const double *m = Q.p;
+    d3 dp = mk3(dw.x * m[0] + dw.y * m[3] + dw.z * m[6], dw.x * m[1] + dw.y * m[4] + dw.z * m[7],
+                dw.x * m[2] + dw.y * m[5] + dw.z * m[8]);
+    return len3(xf_dir(Q.W, dw)) / len3(dp);
+}
+
 // Evaluate an object's postfix program; the result is left in `res`.
 __device__ __noinline__ bool csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, IvList &res, Guards &gd)
 {
@@ -669,7 +680,19 @@ __device__ __noinline__ bool csg_eval(const DevScene &sc, const DevObject &ob, d
             ++sp;
         } else {
             if (sp < 2) return false;
-            if (!csg_apply(op, stack[sp - 2], stack[sp - 1], tmp, gd)) return false;
+            const bool one_missed = stack[sp - 2].n == 0 || stack[sp - 1].n == 0;
+            if (!csg_apply(op & 0x7F, stack[sp - 2], stack[sp - 1], tmp, gd)) return false;
+            if ((word & DEV_PROG_SKIP) && one_missed && tmp.n > 0) {
+                // csg.rs:33-38,216-221: the surviving operand's end points keep this node's space
+                const DevLeaf &Q = sc.leaves[ob.leaf0 + (word & 0xFFFF)];
+                const double f = skip_scale(Q, dw);
+                const uint32_t bit = 1u << (TAG_SKIP_SHIFT + Q.skip_ord - 1);
+                for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
+                    if (i >= 2 * tmp.n) break;
+                    tmp.t[i] *= f;
+                    tmp.tag[i] |= bit;
+                }
+            }
             iv_copy(stack[sp - 2], tmp);
             --sp;
         }

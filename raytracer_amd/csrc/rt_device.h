@@ -38,7 +38,8 @@ enum DevLeafKind {
 struct DevLeaf {
     int32_t kind;
     int32_t identity; // both maps are exactly the identity
-    int32_t pad0, pad1;
+    int32_t skip_ord; // DL_NONE leaf of a DEV_PROG_SKIP word: 1-based ordinal of that node in its object, else 0
+    int32_t pad1;
     DevXform W; // world -> leaf
     DevXform O; // leaf -> world
     double p[DEV_LEAF_PARAMS];
@@ -61,6 +62,14 @@ enum DevRootMode {
 #define DEV_OP_UNION 1
 #define DEV_OP_INTERSECTION 2
 #define DEV_OP_DIFFERENCE 3
+// A union or difference whose own transform rotates or scales: when one operand is missed the reference
+// returns the other's intervals without this node's to_world (csg.rs:33-38,216-221).  The word then carries
+// this flag and, in its low bits, the object-relative index of a DL_NONE leaf with W = world -> node,
+// p[0..8] = linear part of world -> parent, O = (world -> parent) * (node -> world).  csg_eval scales the
+// surviving end points by |d W_node| / |d W_parent| and sets tag bit 12 + skip_ord - 1; the nearest-hit code
+// undoes the scale to find the surface point and takes the normal through O.
+#define DEV_PROG_SKIP (1 << 23)
+#define DEV_MAX_SKIPS 20
 
 struct DevObject {
     int32_t kind;

@@ -269,6 +269,7 @@ struct KdBuilder {
 struct Flattener {
     const rt_scene_desc *d;
     FlatScene &out;
+    int skip_count = 0; // unions/differences of the current object that need DEV_PROG_SKIP
 
     const rt_shape_node &node(int idx) const
     {
@@ -435,19 +436,28 @@ struct Flattener {
         case RT_SHAPE_UNION:
         case RT_SHAPE_INTERSECTION:
         case RT_SHAPE_DIFFERENCE: {
-            // csg.rs:33-38,216-221 return a child's intervals without this node's
-            // to_world when the sibling list is empty.  With a pure translation that
-            // changes nothing; with any other transform the reference's result is
-            // expressed in the wrong space, which the device does not imitate.
-            if (nd.kind != RT_SHAPE_INTERSECTION && !linear_part_is_identity(mat_load(nd.o2w)))
-                throw Err{RT_ERR_UNSUPPORTED,
-                          "union/difference with a rotating or scaling transform of its own: the reference skips "
-                          "the transform when one operand is missed (csg.rs:33-38,216-221); not reproduced"};
+            // csg.rs:33-38,216-221 return one operand's intervals without this node's to_world when
+            // the other operand is missed.  With a pure translation that changes nothing.  With any
+            // other transform the end points stay in this node's space: t scaled, normal short of one
+            // map.  The program word then names a DL_NONE leaf that holds what csg_eval needs to do the
+            // same (DEV_PROG_SKIP): W = world -> this node, p[0..8] = linear part of world -> parent,
+            // O = (world -> parent) * (this node -> world), the map the normal misses.
+            int skip_leaf = -1;
             emit_intervals(nd.child_a, W, O, leaf0);
             emit_intervals(nd.child_b, W, O, leaf0);
+            if (nd.kind != RT_SHAPE_INTERSECTION && !linear_part_is_identity(mat_load(nd.o2w))) {
+                if (skip_count >= DEV_MAX_SKIPS)
+                    throw Err{RT_ERR_UNSUPPORTED, "more than 20 unions/differences with a rotation or scale of their own in one object"};
+                skip_leaf = push_leaf(DL_NONE, W, mat_mul(Wp, O));
+                DevLeaf &Q = out.leaves[skip_leaf];
+                Q.skip_ord = ++skip_count; // post-order: inner nodes get the lower ordinals
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) Q.p[r * 3 + c] = Wp.m[r][c];
+                if (skip_leaf - leaf0 >= DEV_MAX_LEAVES_PER_OBJECT) throw Err{RT_ERR_UNSUPPORTED, "too many primitives in one object"};
+            }
             int op = nd.kind == RT_SHAPE_UNION ? DEV_OP_UNION
                                                : (nd.kind == RT_SHAPE_INTERSECTION ? DEV_OP_INTERSECTION : DEV_OP_DIFFERENCE);
-            out.prog.push_back(op << 24);
+            out.prog.push_back(skip_leaf >= 0 ? ((op << 24) | DEV_PROG_SKIP | (skip_leaf - leaf0)) : (op << 24));
             out.uses_csg = true;
             break;
         }
@@ -729,6 +739,7 @@ struct Flattener {
         obj.leaf0 = (int)out.leaves.size();
         obj.prog0 = (int)out.prog.size();
         obj.frame = -1;
+        skip_count = 0;
         if (ro.material < 0 || (uint32_t)ro.material >= d->n_materials) throw Err{RT_ERR_INVALID, "material index out of range"};
         const rt_material &m = d->materials[ro.material];
         obj.needs_uv = (m.texture >= 0 && d->textures[m.texture].kind != RT_TEX_SOLID) ? 1 : 0;

@@ -224,6 +224,17 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
         d3 pw = o + d * best_t;
         if (ob.kind == DO_LEAF || ob.kind == DO_CSG) {
             const DevLeaf &L = sc.leaves[ob.leaf0 + (best_aux & 0xFFu)];
+            const uint32_t skips = CSG ? (best_aux >> TAG_SKIP_SHIFT) : 0u;
+            if (CSG && skips) {
+                // the hit's t carries the scale of every to_world the reference skipped (DEV_PROG_SKIP);
+                // the surface point is where the ray really meets the leaf
+                double t_surface = best_t;
+                for (int li = 0; li < ob.n_leaves; ++li) {
+                    const DevLeaf &Q = sc.leaves[ob.leaf0 + li];
+                    if (Q.kind == DL_NONE && Q.skip_ord > 0 && ((skips >> (Q.skip_ord - 1)) & 1u)) t_surface /= skip_scale(Q, d);
+                }
+                pw = o + d * t_surface;
+            }
             LeafRay ry = to_leaf(L, o, d);
             d3 ql = L.identity ? pw : xf_point(L.W, pw);
             d3 nl;
@@ -231,6 +242,13 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
             // system.rs:196 normalises every world normal; only a plane's own normal can arrive
             // un-normalised (`normal <0, 2, 0>`), every other shape hands over a unit vector
             n = L.identity ? (L.kind == DL_PLANE ? normalize3(nl) : nl) : normalize3(xf_normal(L.W, nl));
+            if (CSG && skips) {
+                // ... and the normal misses the skipped nodes' maps, innermost first
+                for (int li = 0; li < ob.n_leaves; ++li) {
+                    const DevLeaf &Q = sc.leaves[ob.leaf0 + li];
+                    if (Q.kind == DL_NONE && Q.skip_ord > 0 && ((skips >> (Q.skip_ord - 1)) & 1u)) n = normalize3(xf_normal(Q.O, n));
+                }
+            }
             if (best_aux & TAG_NEG) n = -n;
         } else {
             const DevLeaf &F = sc.leaves[ob.frame];

@@ -64,11 +64,9 @@ def _solid(rng, depth, spread, tx=True, torus=True):
     if k == 3:
         return "torus { radius %s radius %s%s }" % (_f(rng.uniform(0.6, 1.0)), _f(rng.uniform(0.12, 0.3)), t)
     op = ["union", "intersection", "difference"][k - 5]
-    # A union or difference returns one operand's intervals without its own to_world when the other operand is
-    # missed (csg.rs:33-38,216-221), which puts them in the wrong space unless the transform is a translation:
-    # rt_scene_create refuses such scenes (RT_ERR_UNSUPPORTED), so the generator keeps to translations there.
-    if tx and op != "intersection":
-        t = " " + _transform(rng, spread, linear=False)
+    # (A union or difference returns one operand's intervals without its own to_world when the other operand is
+    # missed, csg.rs:33-38,216-221: with a rotation or scale here the shape shows up in two places.  Both sides
+    # reproduce that.)
     # children sit close to each other so that the operation has something to do
     a = _solid(rng, depth - 1, 0.35, tx=rng.random() < 0.7, torus=torus)
     b = _solid(rng, depth - 1, 0.35, tx=rng.random() < 0.7, torus=torus)

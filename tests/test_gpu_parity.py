@@ -484,6 +484,42 @@ object "x" { difference {
     assert np.max(np.abs(got["n"][hit] - ref["n"][hit])) < 1e-9
 
 
+def test_union_and_difference_skip_their_own_to_world(rt):
+    """csg.rs:33-38,216-221: a union or difference hands back one operand's intervals untouched when the ray
+    misses the other operand, i.e. without its own to_world.  With a rotation or scale on that node the hit keeps
+    the node's space (t scaled, normal short of one map) and the shape shows up displaced for those rays.  The
+    device reproduces it (DEV_PROG_SKIP); here two levels of it, under an intersection and beside a difference."""
+    tx = "transform { scale <1.5, 0.7, 1.2> rotate_y 35 rotate_z 20 translate <0.3, 0.2, -0.4> }"
+    inner = "union { sphere { origin <-1.2, 0, 0> radius 0.8 } cube { <0.6, -0.5, -0.5> <1.6, 0.5, 0.5> } %s }"
+    text = ("camera { origin <0, 0, 9> look_at <0, 0, 0> }\n"
+            'object "a" { difference { %s cylinder { radius 0.3 height 4 transform { translate <2.5, 0, 0> } } '
+            "transform { scale <0.8, 1.3, 1> rotate_x 25 } } material { lambertian texture { solid color white } } }\n"
+            'object "b" { intersection { %s sphere { origin <0, 0, 0> radius 5 } transform { translate <0, 3.5, 0> } } '
+            "material { lambertian texture { solid color white } } }\n") % (inner % tx, inner % tx)
+    flat = ("camera { origin <0, 0, 9> look_at <0, 0, 0> }\n"       # the same solids with every map on the leaves
+            'object "s" { sphere { origin <-1.2, 0, 0> radius 0.8 transform { %s scale <0.8, 1.3, 1> rotate_x 25 } } '
+            "material { lambertian texture { solid color white } } }\n") % tx[len("transform { "):-2]
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse(o, text, parity.ASSETS)
+    ro, rd = _random_rays(60000, 21, np.array([0.0, 1.5, 0.0]), 4.0)
+    dev = rt.DeviceScene(sc)
+    got, gst = dev.trace_rays(ro, rd, seed=4)
+    ref, rst = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    same = got["object"] == ref["object"]
+    assert same.mean() >= ID_MATCH_MIN, same.mean()
+    assert (ref["object"] == 0).mean() > 0.05 and (ref["object"] == 1).mean() > 0.05
+    hit = same & (ref["object"] >= 0)
+    scale = np.maximum(1.0, np.abs(ref["t"][hit]))
+    assert np.mean(np.abs(got["t"][hit] - ref["t"][hit]) / scale < HIT_TOL) >= ID_MATCH_MIN
+    assert np.mean(np.all(np.abs(got["n"][hit] - ref["n"][hit]) < 1e-7, axis=1)) >= ID_MATCH_MIN
+    assert list(gst.guards) == list(rst.guards)
+    # and the quirk is what is being compared: the sphere alone, with the composed maps on the leaf, is elsewhere
+    fsc = rt.parse(o, flat, parity.ASSETS)
+    geo, _ = oracle_lib.trace_rays(fsc.desc, ro, rd, seed=4)
+    both = (ref["object"] == 0) & (geo["object"] == 0)
+    assert both.sum() > 500 and np.mean(np.abs(ref["t"][both] - geo["t"][both]) > 1e-3) > 0.5
+
+
 def test_reference_known_answers_on_device(rt):
     """The reference's own unit-test vectors, first hit through rt_trace_rays."""
     for case in GOLD["shape_intervals"]:
