@@ -6,6 +6,27 @@
 #include "rt_device.h"
 
 #define RT_DEV __device__ __forceinline__
+// Waves per SIMD the variants of k_intersect are compiled for.  Measured on MI355X (4K csg.scene /
+// 1080p room.scene / 4K x 4 samples fog_light.scene, ms per frame): evaluators out of line at 1 wave
+// 7.8 / 54 / 17.8; inlined at 2 waves 5.1 / 34.2 / 12.7; inlined at 3 waves 5.2 / 31.9 / 11.7; at 4 waves
+// 5.3 / 30.9 / 12.7 (170 spilled registers in the fog variant).  The torus variants gain nothing from 2.
+#ifndef RT_TORUS_WAVES
+#define RT_TORUS_WAVES 1
+#endif
+#ifndef RT_CSG_WAVES
+#define RT_CSG_WAVES 3
+#endif
+// The CSG evaluators are inlined into the kernel: device functions cannot carry amdgpu_waves_per_eu, so
+// out of line they took 166-250 registers whatever the kernel asked for, and every call passed its
+// interval lists through generic pointers into scratch memory (-DRT_CSG_INLINE=0 restores that).
+#ifndef RT_CSG_INLINE
+#define RT_CSG_INLINE 1
+#endif
+#if RT_CSG_INLINE
+#define RT_CSG_FN __device__ __forceinline__
+#else
+#define RT_CSG_FN __device__ __noinline__
+#endif
 #define RT_PI 3.14159265358979323846
 
 struct d3 {

@@ -73,15 +73,36 @@ RT_DEV Candidate eval_leaf_object(const DevScene &sc, const DevObject &ob, d3 o,
     return c;
 }
 
-__device__ __noinline__ Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
+template <bool TORUS>
+RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
 {
-    IvList res;
-    res.n = 0;
     Candidate c;
     c.ok = false;
     c.t = 0.0;
     c.aux = 0u;
-    if (!csg_eval(sc, ob, o, d, res, gd)) return c;
+    // lists of one interval stay in registers (csg_eval1); anything longer goes through csg_eval
+#if RT_CSG_REG_PATH
+    Iv1 r;
+    const int rc = csg_eval1<TORUS>(sc, ob, o, d, r, gd);
+    if (rc == CSG1_FAIL) return c;
+    if (rc == CSG1_OK) {
+        if (r.n == 0) return c;
+        // first_intersection / first_positive_intersection (shapes/mod.rs:45-55)
+        if (ob.mode == DM_FIRST_ENTRY || !(r.t0 < 0.0)) {
+            c.t = r.t0;
+            c.aux = r.g0;
+            c.ok = true;
+        } else if (!(r.t1 < 0.0)) {
+            c.t = r.t1;
+            c.aux = r.g1;
+            c.ok = true;
+        }
+        return c;
+    }
+#endif
+    IvList res;
+    res.n = 0;
+    if (!csg_eval<TORUS>(sc, ob, o, d, res, gd)) return c;
     return pick_from_list(res, ob.mode);
 }
 
@@ -107,7 +128,7 @@ RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3
 
 // HomogenousMedium::intersect (homogenous_medium.rs:29-57)
 template <bool CSG, bool TORUS>
-__device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
+RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
                                                      d3 d, const PassParams &pp, uint32_t pixel, Guards &gd)
 {
     Candidate c;
@@ -122,7 +143,7 @@ __device__ __noinline__ Candidate eval_medium_object(const DevScene &sc, const D
     res.n = 0;
     if (ob.prog_len == 0) {
         leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
-    } else if (!CSG || !csg_eval(sc, ob, o, d, res, gd)) {
+    } else if (!CSG || !csg_intervals<TORUS>(sc, ob, o, d, res, gd)) {
         return c;
     }
     if (res.n == 0) return c;
@@ -193,7 +214,7 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
         switch (ob.kind) {
         case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
         case DO_CSG:
-            if (CSG) c = eval_csg_object(sc, ob, o, d, gd);
+            if (CSG) c = eval_csg_object<TORUS>(sc, ob, o, d, gd);
             break;
         case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
         default:
