@@ -27,6 +27,15 @@
 #else
 #define RT_CSG_FN __device__ __noinline__
 #endif
+// the quartic chain of the torus (torus_ends -> quartic -> cubic -> quadratic)
+#ifndef RT_TORUS_INLINE
+#define RT_TORUS_INLINE 0
+#endif
+#if RT_TORUS_INLINE
+#define RT_TORUS_FN __device__ __forceinline__
+#else
+#define RT_TORUS_FN __device__ __noinline__
+#endif
 #define RT_PI 3.14159265358979323846
 
 struct d3 {
@@ -133,7 +142,7 @@ RT_DEV cplx ccbrt(cplx c, int n)
 }
 
 // algebra.rs:40-58
-__device__ __noinline__ int dev_solve_quadratic(cplx a, cplx b, cplx c, cplx *r)
+RT_TORUS_FN int dev_solve_quadratic(cplx a, cplx b, cplx c, cplx *r)
 {
     if (cis_zero(a)) {
         if (cis_zero(b)) return 0;
@@ -152,7 +161,7 @@ __device__ __noinline__ int dev_solve_quadratic(cplx a, cplx b, cplx c, cplx *r)
 }
 
 // algebra.rs:60-86
-__device__ __noinline__ int dev_solve_cubic(cplx a, cplx b, cplx c, cplx d, cplx *r)
+RT_TORUS_FN int dev_solve_cubic(cplx a, cplx b, cplx c, cplx d, cplx *r)
 {
     if (cis_zero(a)) return dev_solve_quadratic(b, c, d, r);
     b = b / a;
@@ -172,7 +181,7 @@ __device__ __noinline__ int dev_solve_cubic(cplx a, cplx b, cplx c, cplx d, cplx
 }
 
 // algebra.rs:88-156: real coefficients in, real roots (|im| < 1e-8) out, unsorted
-__device__ __noinline__ int dev_solve_quartic_f64(double ar, double br, double cr, double dr, double er, double *roots)
+RT_TORUS_FN int dev_solve_quartic_f64(double ar, double br, double cr, double dr, double er, double *roots)
 {
     cplx r[4];
     int n;

@@ -67,7 +67,7 @@ RT_DEV d3 axis_vec(int a, double s) { return mk3(a == 0 ? s : 0.0, a == 1 ? s : 
 // Leaf-space end points of one primitive.  Returns the number of end points
 // (0, 2 or 4; intervals are consecutive pairs), t[] in leaf space, sub[] =
 // part | TAG_NEG.
-__device__ __noinline__ int torus_ends(const double *p, d3 o, d3 d, double *t, uint32_t *sub, Guards &gd)
+RT_TORUS_FN int torus_ends(const double *p, d3 o, d3 d, double *t, uint32_t *sub, Guards &gd)
 {
     // torus.rs:52-125
     double R = p[0], S = p[1];
@@ -700,197 +700,6 @@ RT_CSG_FN bool csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, I
     }
     if (sp != 1) return false;
     iv_copy(res, stack[0]);
-    return true;
-}
-
-// ---------------------------------------------------------------------------
-// The same program with every list held in registers, for as long as no list needs more than one
-// interval (nearly always: a ray meets a convex operand in one interval, and most unions, intersections
-// and differences of two single intervals are single again).  The four stack slots are plain structs
-// picked by compare-and-select, so nothing here touches scratch memory.  Returns CSG1_BAIL as soon as a
-// list would hold two intervals (a torus met twice, a union of two separate intervals, a difference that
-// cuts an interval in two): the caller then runs csg_eval from the start, and the guard counts of the
-// attempt are dropped with it.
-#ifndef RT_CSG_REG_PATH
-#define RT_CSG_REG_PATH 0
-#endif
-struct Iv1 {
-    double t0, t1;
-    uint32_t g0, g1;
-    int n; // 0 or 1
-};
-#define CSG1_OK 0
-#define CSG1_BAIL 1
-#define CSG1_FAIL 2 // what csg_eval reports as false: a reference panic or a program the stack cannot hold
-
-RT_DEV Iv1 iv1_get(int k, const Iv1 &a, const Iv1 &b, const Iv1 &c, const Iv1 &d)
-{
-    Iv1 r = a;
-    if (k == 1) r = b;
-    if (k == 2) r = c;
-    if (k == 3) r = d;
-    return r;
-}
-RT_DEV void iv1_put(int k, const Iv1 &v, Iv1 &a, Iv1 &b, Iv1 &c, Iv1 &d)
-{
-    if (k == 0) a = v;
-    if (k == 1) b = v;
-    if (k == 2) c = v;
-    if (k == 3) d = v;
-}
-
-// csg.rs:28-98 / 133-176 / 211-280 for operands of at most one interval
-RT_DEV int csg_apply1(int op, const Iv1 &A, const Iv1 &B, Iv1 &out, Guards &gd)
-{
-    out.n = 0;
-    out.t0 = out.t1 = 0.0;
-    out.g0 = out.g1 = 0u;
-    if (op == DEV_OP_UNION) {
-        if (A.n == 0) {
-            out = B;
-            return CSG1_OK;
-        }
-        if (B.n == 0) {
-            out = A;
-            return CSG1_OK;
-        }
-        if (A.t1 < B.t0 || B.t1 < A.t0) return CSG1_BAIL; // two separate intervals
-        // Overlapping: the merged interval, and then a again unless b's end moved the merge past it
-        // (csg.rs:62-64 advances a only then; :78-79 push what is left in hand): two intervals.
-        if (!(B.t1 > A.t1)) return CSG1_BAIL;
-        out = A;
-        if (B.t0 < out.t0) {
-            out.t0 = B.t0;
-            out.g0 = B.g0;
-        }
-        out.t1 = B.t1;
-        out.g1 = B.g1;
-        return CSG1_OK;
-    }
-    if (op == DEV_OP_INTERSECTION) {
-        if (A.n == 0 || B.n == 0) return CSG1_OK;
-        if (A.t1 < B.t0 || B.t1 < A.t0) return CSG1_OK;
-        const bool s_from_a = A.t0 > B.t0, e_from_a = A.t1 < B.t1;
-        out.t0 = s_from_a ? A.t0 : B.t0;
-        out.g0 = s_from_a ? A.g0 : B.g0;
-        out.t1 = e_from_a ? A.t1 : B.t1;
-        out.g1 = e_from_a ? A.g1 : B.g1;
-        out.n = 1;
-        return CSG1_OK;
-    }
-    // difference
-    if (A.n == 0) return CSG1_OK;
-    if (B.n == 0 || A.t1 < B.t0 || B.t1 < A.t0) {
-        out = A;
-        return CSG1_OK;
-    }
-    if (B.t0 <= A.t0 && B.t1 >= A.t1) return CSG1_OK; // b covers a
-    if (B.t0 <= A.t0 && B.t1 < A.t1) {               // b overlaps a's start
-        out = A;
-        out.t0 = B.t1;
-        out.g0 = B.g1 ^ TAG_NEG;
-        return CSG1_OK;
-    }
-    if (B.t0 < A.t1 && B.t1 < A.t1) return CSG1_BAIL; // b cuts a in two
-    if (B.t0 < A.t1 && B.t1 >= A.t1) {                // b overlaps a's end
-        out = A;
-        out.t1 = B.t0;
-        out.g1 = B.g0 ^ TAG_NEG;
-        return CSG1_OK;
-    }
-    gd.g[2]++; // "unanticipated difference case" (csg.rs:262), NaNs
-    return CSG1_FAIL;
-}
-
-template <bool TORUS>
-RT_DEV int csg_eval1(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, Iv1 &res, Guards &gd_out)
-{
-    Guards gd;
-    for (int i = 0; i < 5; ++i) gd.g[i] = 0u;
-    gd.overflow = 0u;
-    Iv1 s0, s1, s2, s3;
-    s0.n = s1.n = s2.n = s3.n = 0;
-    s0.t0 = s0.t1 = s1.t0 = s1.t1 = s2.t0 = s2.t1 = s3.t0 = s3.t1 = 0.0;
-    s0.g0 = s0.g1 = s1.g0 = s1.g1 = s2.g0 = s2.g1 = s3.g0 = s3.g1 = 0u;
-    int sp = 0;
-    int rc = CSG1_OK;
-    for (int pc = 0; pc < ob.prog_len; ++pc) {
-        const int word = sc.prog[ob.prog0 + pc];
-        const int op = (word >> 24) & 0x7F;
-        Iv1 v;
-        v.n = 0;
-        v.t0 = v.t1 = 0.0;
-        v.g0 = v.g1 = 0u;
-        if (op == DEV_OP_LEAF) {
-            if (sp >= DEV_CSG_STACK) {
-                gd.overflow++;
-                rc = CSG1_FAIL;
-                break;
-            }
-            const uint32_t rel = (uint32_t)(word & 0xFFFFFF);
-            const DevLeaf &L = sc.leaves[ob.leaf0 + rel];
-            LeafRay ry = to_leaf(L, ow, dw);
-            double t[4];
-            uint32_t sub[4];
-            const int n = leaf_ends<TORUS>(L, ry, t, sub, gd);
-            if (n > 2) {
-                rc = CSG1_BAIL;
-                break;
-            }
-            if (n == 2) {
-                v.t0 = leaf_t_to_world(L, ow, ry, t[0]);
-                v.t1 = leaf_t_to_world(L, ow, ry, t[1]);
-                v.g0 = sub[0] | rel;
-                v.g1 = sub[1] | rel;
-                v.n = 1;
-            }
-            iv1_put(sp, v, s0, s1, s2, s3);
-            ++sp;
-        } else {
-            if (sp < 2) {
-                rc = CSG1_FAIL;
-                break;
-            }
-            const Iv1 A = iv1_get(sp - 2, s0, s1, s2, s3), B = iv1_get(sp - 1, s0, s1, s2, s3);
-            rc = csg_apply1(op, A, B, v, gd);
-            if (rc != CSG1_OK) break;
-            if ((word & DEV_PROG_SKIP) && (A.n == 0 || B.n == 0) && v.n > 0) {
-                const DevLeaf &Q = sc.leaves[ob.leaf0 + (word & 0xFFFF)];
-                const double f = skip_scale(Q, dw);
-                const uint32_t bit = 1u << (TAG_SKIP_SHIFT + Q.skip_ord - 1);
-                v.t0 *= f;
-                v.t1 *= f;
-                v.g0 |= bit;
-                v.g1 |= bit;
-            }
-            iv1_put(sp - 2, v, s0, s1, s2, s3);
-            --sp;
-        }
-    }
-    if (rc == CSG1_BAIL) return rc;
-    if (rc == CSG1_OK && sp != 1) rc = CSG1_FAIL;
-    for (int i = 0; i < 5; ++i) gd_out.g[i] += gd.g[i];
-    gd_out.overflow += gd.overflow;
-    res = s0;
-    return rc;
-}
-
-// An object's intervals: the register path first, the general one when a list outgrows it.
-template <bool TORUS>
-RT_DEV bool csg_intervals(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, IvList &res, Guards &gd)
-{
-#if !RT_CSG_REG_PATH
-    return csg_eval<TORUS>(sc, ob, ow, dw, res, gd);
-#endif
-    Iv1 r;
-    const int rc = csg_eval1<TORUS>(sc, ob, ow, dw, r, gd);
-    if (rc == CSG1_BAIL) return csg_eval<TORUS>(sc, ob, ow, dw, res, gd);
-    if (rc == CSG1_FAIL) return false;
-    res.n = r.n;
-    res.t[0] = r.t0;
-    res.t[1] = r.t1;
-    res.tag[0] = r.g0;
-    res.tag[1] = r.g1;
     return true;
 }
 

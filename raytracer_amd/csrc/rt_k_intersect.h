@@ -80,26 +80,6 @@ RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 
     c.ok = false;
     c.t = 0.0;
     c.aux = 0u;
-    // lists of one interval stay in registers (csg_eval1); anything longer goes through csg_eval
-#if RT_CSG_REG_PATH
-    Iv1 r;
-    const int rc = csg_eval1<TORUS>(sc, ob, o, d, r, gd);
-    if (rc == CSG1_FAIL) return c;
-    if (rc == CSG1_OK) {
-        if (r.n == 0) return c;
-        // first_intersection / first_positive_intersection (shapes/mod.rs:45-55)
-        if (ob.mode == DM_FIRST_ENTRY || !(r.t0 < 0.0)) {
-            c.t = r.t0;
-            c.aux = r.g0;
-            c.ok = true;
-        } else if (!(r.t1 < 0.0)) {
-            c.t = r.t1;
-            c.aux = r.g1;
-            c.ok = true;
-        }
-        return c;
-    }
-#endif
     IvList res;
     res.n = 0;
     if (!csg_eval<TORUS>(sc, ob, o, d, res, gd)) return c;
@@ -143,7 +123,7 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
     res.n = 0;
     if (ob.prog_len == 0) {
         leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
-    } else if (!CSG || !csg_intervals<TORUS>(sc, ob, o, d, res, gd)) {
+    } else if (!CSG || !csg_eval<TORUS>(sc, ob, o, d, res, gd)) {
         return c;
     }
     if (res.n == 0) return c;
