@@ -267,6 +267,17 @@ int rt_trace_rays(rt_scene *scene, uint64_t seed, uint64_t n, const double *orig
  * strata + 1.  Host buffers. */
 int rt_tonemap(const double *rgb_sum, uint64_t n_pixels, double divisor, uint8_t *rgb8);
 
+/* The same pixel math as a kernel on `stream` (hipStream_t or NULL), device
+ * buffers in and out: a frame that is only wanted as an image leaves the GPU
+ * as 3 bytes per pixel instead of 24. */
+int rt_tonemap_device(const double *d_rgb_sum, uint64_t n_pixels, double divisor, uint8_t *d_rgb8, void *stream);
+
+/* The file half of write_render_result_to_file (main.rs:219-227): an 8-bit
+ * RGB PNG of a tone-mapped frame, rows top to bottom as in the render buffer.
+ * (The pixels are the reference's; the compressed bytes depend on the encoder
+ * and are not comparable with image 0.14's.) */
+int rt_write_png(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
+
 /* Thread-local message for the last non-zero status. */
 const char *rt_last_error(void);
 

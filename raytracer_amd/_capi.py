@@ -108,6 +108,8 @@ SIGNATURES = {
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(rt_hit), C.POINTER(rt_stats)]),
     "rt_tonemap": (C.c_int, [C.POINTER(C.c_double), C.c_uint64, C.c_double, C.POINTER(C.c_uint8)]),
+    "rt_tonemap_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]),
+    "rt_write_png": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]),
     "rt_last_error": (C.c_char_p, []),
     "rt_sdl_parse": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(rt_scene_desc))]),
     "rt_sdl_parse_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32,

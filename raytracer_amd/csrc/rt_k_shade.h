@@ -316,6 +316,28 @@ __global__ void k_fill_background(DevScene sc, rt_shard_geom g, uint32_t rank, u
     }
 }
 
+// main.rs:201-217 per channel: (sum / divisor).sqrt() * 255, min 255, `as u8` (saturating; NaN -> 255 through
+// f64::min, then 255).  Four channels per thread, one 32-bit store; the last thread takes what is left.
+__global__ void k_tonemap(const double *__restrict__ rgb_sum, uint64_t n_values, double divisor, uint8_t *__restrict__ rgb8)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n_values) return;
+    uint32_t packed = 0u;
+    const uint32_t n = (uint32_t)((n_values - i) < 4 ? (n_values - i) : 4);
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k >= n) break;
+        double v = sqrt(rgb_sum[i + k] / divisor) * 255.0;
+        v = (v != v) ? 255.0 : (v < 255.0 ? v : 255.0);
+        const uint32_t b = v <= 0.0 ? 0u : (uint32_t)v;
+        packed |= b << (8 * k);
+    }
+    if (n == 4 && ((uintptr_t)(rgb8 + i) & 3u) == 0) {
+        *(uint32_t *)(rgb8 + i) = packed;
+    } else {
+        for (uint32_t k = 0; k < n; ++k) rgb8[i + k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
 __global__ void k_unshard(rt_shard_geom g, uint32_t rank, uint32_t n_slots, const double *shard_rgb, double *full_rgb,
                           const int32_t *shard_ids, int32_t *full_ids)
 {

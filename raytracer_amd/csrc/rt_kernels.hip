@@ -630,6 +630,24 @@ extern "C" int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, co
     return RT_OK;
 }
 
+extern "C" int rt_tonemap_device(const double *d_rgb_sum, uint64_t n_pixels, double divisor, uint8_t *d_rgb8, void *stream)
+{
+    if (!d_rgb_sum || !d_rgb8) {
+        rt_host::set_last_error("rt_tonemap_device: null argument");
+        return RT_ERR_INVALID;
+    }
+    const uint64_t n_values = n_pixels * 3, threads = (n_values + 3) / 4;
+    if (threads == 0) return RT_OK;
+    if ((threads + 255) / 256 > 0x7FFFFFFFull) {
+        rt_host::set_last_error("rt_tonemap_device: image too large for one launch");
+        return RT_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_tonemap, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rgb_sum, n_values,
+                       divisor, d_rgb8);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 struct HostRenderCtx {
     const rt_options *opts;
     double *d_full_rgb; // row-major running sum on the device

@@ -188,3 +188,19 @@ def tonemap(rgb_sum, divisor):
                         out.ctypes.data_as(C.POINTER(C.c_uint8)))
     _check(lib, rc, "rt_tonemap")
     return out
+
+
+def tonemap_device(d_rgb_sum_ptr, n_pixels, divisor, d_rgb8_ptr, stream=None):
+    """The same pixel math as a kernel: device pointers (ints) in and out."""
+    from . import lib
+    _check(lib, lib.rt_tonemap_device(d_rgb_sum_ptr, int(n_pixels), float(divisor), d_rgb8_ptr, stream), "rt_tonemap_device")
+
+
+def write_png(path, rgb8):
+    """write_render_result_to_file's file half (main.rs:219-227): rgb8 is an (H, W, 3) uint8 array."""
+    from . import lib
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("write_png wants an (H, W, 3) uint8 array")
+    rc = lib.rt_write_png(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0])
+    _check(lib, rc, "rt_write_png")

@@ -520,6 +520,39 @@ def test_union_and_difference_skip_their_own_to_world(rt):
     assert both.sum() > 500 and np.mean(np.abs(ref["t"][both] - geo["t"][both]) > 1e-3) > 0.5
 
 
+def test_tonemap_kernel_equals_host_pixel_math(rt, tmp_path):
+    """rt_tonemap_device against rt_tonemap and the oracle (main.rs:201-217), incl. NaN, negative and over-range
+    sums, sizes that are no multiple of 4 and an output that is not 4-byte aligned; then a rendered frame to PNG."""
+    import torch
+    rng = np.random.default_rng(3)
+    for n_px in (1, 5, 1000, 1920 * 1080 + 1):
+        vals = rng.uniform(-0.2, 3.0, (n_px, 3))
+        vals[rng.integers(0, n_px, 3), rng.integers(0, 3, 3)] = np.nan
+        vals[0, 0] = 1e300
+        d_in = torch.from_numpy(vals).cuda()
+        d_out = torch.zeros(n_px * 3 + 1, dtype=torch.uint8, device="cuda")
+        for off in (0, 1):
+            rt.tonemap_device(d_in.data_ptr(), n_px, 2.0, d_out.data_ptr() + off)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()[off:off + n_px * 3].reshape(n_px, 3)
+            assert np.array_equal(got, rt.tonemap(vals, 2.0))
+            assert np.array_equal(got, oracle_lib.tonemap(vals, 2.0))
+    from PIL import Image
+    o = rt.Options(width=96, height=64, samples=4, seed=2)
+    sc = rt.parse_file(o, parity.scene_path("three-spheres"), parity.ASSETS)
+    rgb, ids, st = rt.render(o, sc)
+    ref, _, _ = oracle_lib.render(sc.desc, o.to_c(), threads=8)
+    d_rgb = torch.from_numpy(rgb).cuda()
+    d_img = torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda")
+    rt.tonemap_device(d_rgb.data_ptr(), 96 * 64, st.strata + 1, d_img.data_ptr())
+    torch.cuda.synchronize()
+    rt.write_png(tmp_path / "out.png", d_img.cpu().numpy())
+    with Image.open(tmp_path / "out.png") as im:
+        img = np.asarray(im).astype(int)
+    want = oracle_lib.tonemap(ref, st.strata + 1).astype(int)
+    assert np.abs(img - want).max() <= 1 and np.mean(img != want) < 1e-3
+
+
 def test_reference_known_answers_on_device(rt):
     """The reference's own unit-test vectors, first hit through rt_trace_rays."""
     for case in GOLD["shape_intervals"]:

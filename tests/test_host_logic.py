@@ -173,6 +173,23 @@ def test_tonemap_matches_reference_pixel_math(rt):
     assert list(out[1]) == [255, 255, 255] or list(out[1])[0] == 255
 
 
+def test_png_file_holds_the_pixels(rt, tmp_path):
+    """write_render_result_to_file's file half (main.rs:219-227): an 8-bit RGB PNG, rows top to bottom."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    for w, h in ((1, 1), (37, 11), (640, 480)):
+        px = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = tmp_path / ("t%dx%d.png" % (w, h))
+        rt.write_png(path, px)
+        with Image.open(path) as im:
+            assert im.mode == "RGB" and im.size == (w, h)
+            assert np.array_equal(np.asarray(im), px)
+    with pytest.raises(RuntimeError, match="cannot open"):
+        rt.write_png(tmp_path / "no_such_dir" / "x.png", px)
+    with pytest.raises(ValueError):
+        rt.write_png(tmp_path / "x.png", px[:, :, 0])
+
+
 def test_no_gpu_is_a_loud_error(rt):
     import torch
     if torch.cuda.is_available():
