@@ -12,6 +12,7 @@
 //   * images: JPEG decoding (image 0.14 / jpeg-decoder) is not reproduced; an
 //     `image "x.jpg"` texture loads the binary PPM `x.ppm` next to it.
 #include "../../include/rt_api.h"
+#include "host_jpeg.h"
 #include "host_math.h"
 
 #include <cctype>
@@ -190,6 +191,26 @@ static int load_image(SceneOwner &sc, const std::string &path)
     size_t dot = p.find_last_of('.');
     std::string ext = dot == std::string::npos ? "" : p.substr(dot);
     for (char &c : ext) c = (char)std::tolower((unsigned char)c);
+    if (ext == ".jpg" || ext == ".jpeg") {
+        // image::open (sdl.rs:52): decoded here by host_jpeg.cpp.  A file that is absent falls through to a
+        // decoded PPM of the same name, which is how the fixtures pin the texel bytes of earth.jpg.
+        std::ifstream jf(p, std::ios::binary);
+        if (jf) {
+            std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(jf)), std::istreambuf_iterator<char>());
+            int w = 0, h = 0;
+            std::vector<uint8_t> rgb;
+            std::string err;
+            if (!decode_jpeg(bytes.data(), bytes.size(), w, h, rgb, err))
+                throw ParseError{RT_ERR_IO, "could not decode image file: " + p + ": " + err};
+            rt_image im;
+            im.width = (uint32_t)w;
+            im.height = (uint32_t)h;
+            im.offset = sc.image_data.size();
+            sc.image_data.insert(sc.image_data.end(), rgb.begin(), rgb.end());
+            sc.images.push_back(im);
+            return (int)sc.images.size() - 1;
+        }
+    }
     if (ext != ".ppm") p = (dot == std::string::npos ? p : p.substr(0, dot)) + ".ppm";
     std::ifstream f(p, std::ios::binary);
     if (!f) throw ParseError{RT_ERR_IO, "could not open image file: " + p + " (decoded PPM stand-in for " + path + ")"};

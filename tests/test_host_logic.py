@@ -173,6 +173,55 @@ def test_tonemap_matches_reference_pixel_math(rt):
     assert list(out[1]) == [255, 255, 255] or list(out[1])[0] == 255
 
 
+def _texture_bytes(rt, base_dir, name):
+    text = ('camera { origin <0,0,5> look_at <0,0,0> }\nobject "x" { sphere { origin <0,0,0> radius 1 } '
+            'material { lambertian texture { image "%s" 1.0 } } }\n' % name)
+    sc = rt.parse(rt.Options(width=8, height=8), text, str(base_dir))
+    d = sc.desc.contents
+    im = d.images[0]
+    buf = np.ctypeslib.as_array(d.image_data, (im.offset + im.width * im.height * 3,))[im.offset:]
+    return buf.reshape(im.height, im.width, 3).astype(int)
+
+
+def test_jpeg_textures_decode_like_libjpeg(rt, tmp_path):
+    """`image "x.jpg"` (sdl.rs:52, image 0.14 / jpeg-decoder 0.1.22 in the reference): host_jpeg.cpp decodes
+    baseline files.  Decoders differ in the rounding of IDCT, upsampling and colour conversion, so the check is
+    against PIL (libjpeg) within 3 levels and 0.2 on average; texel parity with the reference is unpinned."""
+    from PIL import Image
+    src = os.path.join(parity.ASSETS, "jpeg", "earth.jpg")           # the reference's own texture
+    ref = np.asarray(Image.open(src).convert("RGB")).astype(int)
+    got = _texture_bytes(rt, os.path.dirname(src), "earth.jpg")
+    assert got.shape == ref.shape == (378, 756, 3)
+    d = np.abs(got - ref)
+    assert d.max() <= 3 and d.mean() < 0.1
+    # 4:4:4, 4:2:2, 4:2:0, odd sizes, restart intervals, greyscale
+    cases = [(64, 48, 0, 90, {}), (67, 45, 1, 85, {}), (123, 77, 2, 75, {}), (33, 17, 2, 95, {}),
+             (200, 100, 2, 50, {"restart_marker_blocks": 7}), (16, 16, 0, 100, {}), (1, 1, 2, 80, {})]
+    for w, h, sub, q, kw in cases:
+        im = Image.fromarray(ref[:h * 3:3, :w * 3:3][:h, :w].astype(np.uint8))
+        try:
+            im.save(tmp_path / "t.jpg", quality=q, subsampling=sub, **kw)
+        except TypeError:
+            im.save(tmp_path / "t.jpg", quality=q, subsampling=sub)
+        want = np.asarray(Image.open(tmp_path / "t.jpg").convert("RGB")).astype(int)
+        d = np.abs(_texture_bytes(rt, tmp_path, "t.jpg") - want)
+        assert d.max() <= 3 and d.mean() < 0.2, (w, h, sub, q, d.max(), d.mean())
+    Image.fromarray(ref[:40, :50].astype(np.uint8)).convert("L").save(tmp_path / "g.jpg", quality=90)
+    want = np.asarray(Image.open(tmp_path / "g.jpg").convert("RGB")).astype(int)
+    assert np.abs(_texture_bytes(rt, tmp_path, "g.jpg") - want).max() <= 1
+    # what it does not cover is refused with a reason, like the reference's expect("could not open image file")
+    Image.fromarray(ref[:40, :50].astype(np.uint8)).save(tmp_path / "p.jpg", quality=90, progressive=True)
+    with pytest.raises(Exception, match="progressive"):
+        _texture_bytes(rt, tmp_path, "p.jpg")
+    data = open(src, "rb").read()
+    open(tmp_path / "cut.jpg", "wb").write(data[:300])
+    with pytest.raises(Exception, match="could not decode image file"):
+        _texture_bytes(rt, tmp_path, "cut.jpg")
+    open(tmp_path / "half.jpg", "wb").write(data[:len(data) // 2])      # the entropy-coded data ends early
+    with pytest.raises(Exception, match="restart marker"):
+        _texture_bytes(rt, tmp_path, "half.jpg")
+
+
 def test_png_file_holds_the_pixels(rt, tmp_path):
     """write_render_result_to_file's file half (main.rs:219-227): an 8-bit RGB PNG, rows top to bottom."""
     from PIL import Image
