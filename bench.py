@@ -147,6 +147,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed region runs with the per-kernel HIP events on (RT_FLAG_STAGE_TIMES): the roofline figure must
+    # come from events on the launch stream inside it.  They cost about 3 % of the frame; `uninstrumented`
+    # repeats the same steps without them.
+    opts.stage_times = True
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -168,14 +172,24 @@ def main():
         acc["mesh_rays"] += st.mesh_rays
     barrier()
     dt = time.perf_counter() - t0
+    opts.stage_times = False
+    step(0)
+    barrier()
+    t1 = time.perf_counter()
+    rays_plain = 0
+    for k in range(args.steps):
+        rays_plain += step(args.warmup + k).rays
+    barrier()
+    dt_plain = time.perf_counter() - t1
 
     if world > 1:
-        t = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([dt, float(rays), dt_plain], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
+        dt_plain = float(tmax[2])
         rays_total = float(tsum[1])
     else:
         rays_total = float(rays)
@@ -215,6 +229,9 @@ def main():
                        "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps},
             "roofline": roof,
             "kernels": kernels[1:],
+            # the same K steps again without the per-kernel events of the timed region (what rt_render costs a caller
+            # that does not ask for stage times)
+            "uninstrumented": {"value": rays_total / dt_plain / 1e6, "unit": "Mrays/s", "ms_per_step": dt_plain / args.steps * 1e3},
             "stage_ms_per_step": {"raygen": acc["ms_raygen"] / args.steps, "intersect": acc["ms_int"] / args.steps,
                                   "mesh": acc["ms_mesh"] / args.steps, "shade": acc["ms_shade"] / args.steps,
                                   "tail": acc["ms_tail"] / args.steps},

@@ -177,6 +177,9 @@ typedef struct rt_options {
 #define RT_FLAG_ROW_MAJOR 1u /* shard_count == 1 only: outputs are indexed y * width + x instead of by shard
                              * slot (width * height elements), so a whole image needs no rt_unshard_device */
 
+#define RT_FLAG_STAGE_TIMES 2u /* fill rt_stats.ms_raygen .. ms_tail: four HIP events per bounce pass on the launch
+                               * stream, which cost about 3 % of a 4K frame; without the flag those fields are 0 */
+
 typedef struct rt_stats {
     uint64_t rays;         /* Ray::trace invocations, primary + secondary  */
     uint64_t primary_rays; /* of which depth 0                             */

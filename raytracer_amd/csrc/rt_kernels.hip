@@ -310,7 +310,7 @@ static int check_options(const rt_options *o)
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
 // nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the mesh pass
-// returns 1 when the grid walk (k_mesh) ran, 0 otherwise; `mid` is recorded between the two stages
+// returns 1 when the grid walk (k_mesh) ran, 0 otherwise; `mid` (if any) is recorded between the two stages
 static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
                             uint32_t *mesh_count, const PassParams &pp, int32_t *ids, hipEvent_t mid)
 {
@@ -330,7 +330,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
     default: LAUNCH_I(true, true, true); break;
     }
 #undef LAUNCH_I
-    (void)hipEventRecord(mid, st);
+    if (mid) (void)hipEventRecord(mid, st);
     int walked = 0;
     if (s->has_mesh) {
         // short queues: one wave per ray over all triangles; long queues: one lane per ray through the mesh grid
@@ -389,6 +389,8 @@ static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQue
 typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
 
 // the wavefront loop for one shard; d_rgb (sum) and d_ids are in shard layout
+// per-kernel events, recorded only when the caller asked for stage times (RT_FLAG_STAGE_TIMES)
+#define STAGE_EV(CALL) do { if (stage_times) HIP_TRY(CALL); } while (0)
 static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int32_t *d_ids, rt_stats *stats,
                          hipStream_t st, stratum_fn per_stratum, void *user)
 {
@@ -425,6 +427,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
     HIP_TRY(hipEventRecord(s->ev0, st));
     RT_TRACE("event recorded");
     const bool row_major = (opts->flags & RT_FLAG_ROW_MAJOR) != 0u; // check_options: only with a single shard
+    const bool stage_times = (opts->flags & RT_FLAG_STAGE_TIMES) != 0u;
     const size_t n_out = row_major ? (size_t)opts->width * opts->height : (size_t)n_slots;
     HIP_TRY(hipMemsetAsync(d_rgb, 0, n_out * 3 * sizeof(double), st)); // alloc_render_buf
     if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xFF, n_out * sizeof(int32_t), st));
@@ -456,7 +459,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 q_primary.g = g;
                 q_primary.recip_sqrt_spp = recip;
                 HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_counts, (int)n_slots, 1, st));
-                HIP_TRY(hipEventRecord(s->evp[0], st));
+                STAGE_EV(hipEventRecord(s->evp[0], st));
                 // `live` bounds the rays of the next pass from above: the newest count that has come
                 // back (counts never grow).  The kernels read the true count on the device; the bound
                 // only sizes grids and picks between k_mesh and k_mesh_brute.
@@ -474,15 +477,15 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
-                    HIP_TRY(hipEventRecord(s->evp[1 + 4 * depth], st));
+                    STAGE_EV(hipEventRecord(s->evp[1 + 4 * depth], st));
                     const RayQueue &q_in = depth == 0 ? q_primary : s->q[cur];
                     walked[depth] = (uint8_t)launch_intersect(s, st, live, q_in, s->d_counts + depth,
                                                               s->d_counts + (opts->max_depth + 2) + depth, pp, ids,
-                                                              s->evp[2 + 4 * depth]);
-                    HIP_TRY(hipEventRecord(s->evp[3 + 4 * depth], st));
+                                                              stage_times ? s->evp[2 + 4 * depth] : nullptr);
+                    STAGE_EV(hipEventRecord(s->evp[3 + 4 * depth], st));
                     hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st, s->dev, q_in,
                                        s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
-                    HIP_TRY(hipEventRecord(s->evp[4 + 4 * depth], st));
+                    STAGE_EV(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;
                     // queue length of the next pass: copied back asynchronously after every pass.  The
@@ -506,9 +509,9 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     if (live <= tail_max && depth + 1 < opts->max_depth) {
                         // few paths left: one launch takes them all to their ends
                         pp.depth = depth + 1;
-                        HIP_TRY(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
+                        STAGE_EV(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
                         launch_tail(s, st, live, s->q[cur], pp, d_rgb);
-                        HIP_TRY(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
+                        STAGE_EV(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
                         tail_at = (int)depth + 1;
                         break;
                     }
@@ -545,7 +548,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     if (lane_totals[0] && lane_totals[1] + 1 > levels) levels = lane_totals[1] + 1;
                 }
                 if (levels > local.bounce_passes) local.bounce_passes = levels; // (strata share the levels)
-                {
+                if (stage_times) {
                     float ms_k = 0.f;
                     HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[0], s->evp[1]));
                     local.ms_raygen += ms_k;
@@ -755,7 +758,7 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     pp.force_uv = 1;
     pp.bias = 0.0;
     HIP_TRY(hipMemset(s->d_counts + 3, 0, sizeof(uint32_t)));
-    (void)launch_intersect(s, nullptr, n32, s->q[0], s->d_counts, s->d_counts + 3, pp, nullptr, s->evp[2]);
+    (void)launch_intersect(s, nullptr, n32, s->q[0], s->d_counts, s->d_counts + 3, pp, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<int32_t> obj(n);

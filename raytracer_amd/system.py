@@ -9,6 +9,10 @@ import numpy as np
 from . import _capi
 
 
+ROW_MAJOR = 1  # RT_FLAG_ROW_MAJOR
+STAGE_TIMES = 2  # RT_FLAG_STAGE_TIMES: per-kernel times in rt_stats (costs about 3 % of a frame)
+
+
 @dataclass
 class Options:
     """system.rs:18-26; defaults are main.rs:50-88.  `seed` keys the
@@ -21,14 +25,16 @@ class Options:
     samples: int = 1
     seed: int = 1
     tile_size: int = 64
+    stage_times: bool = False  # RT_FLAG_STAGE_TIMES: per-kernel times in rt_stats (about 3 % of a 4K frame)
 
     def to_c(self, shard_rank=0, shard_count=1, flags=0):
+        if self.stage_times:
+            flags |= STAGE_TIMES
         return _capi.rt_options(width=self.width, height=self.height, samples=self.samples, max_depth=self.max_depth,
                                 bias=self.bias, seed=self.seed, tile_size=self.tile_size, shard_rank=shard_rank,
                                 shard_count=shard_count, flags=flags)
 
 
-ROW_MAJOR = 1  # RT_FLAG_ROW_MAJOR
 
 
 class RenderProgress:
@@ -94,10 +100,12 @@ class DeviceScene:
             progress.render_finished(options, rgb)
         return rgb, ids, stats
 
-    def render_shard(self, options, shard_rank, shard_count, d_rgb_ptr, d_ids_ptr=None, stream=None, row_major=False):
+    def render_shard(self, options, shard_rank, shard_count, d_rgb_ptr, d_ids_ptr=None, stream=None, row_major=False,
+                     stage_times=False):
         """One shard of the tiles into caller-owned device buffers (rt_render_device).  `row_major`
-        (a single shard only): the buffers are width * height elements indexed y * width + x."""
-        o = options.to_c(shard_rank, shard_count, ROW_MAJOR if row_major else 0)
+        (a single shard only): the buffers are width * height elements indexed y * width + x.
+        `stage_times`: fill the per-kernel times of the returned rt_stats."""
+        o = options.to_c(shard_rank, shard_count, (ROW_MAJOR if row_major else 0) | (STAGE_TIMES if stage_times else 0))
         stats = _capi.rt_stats()
         rc = self._lib.rt_render_device(self._h, C.byref(o), C.c_void_p(d_rgb_ptr),
                                         C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(stats),

@@ -203,10 +203,15 @@ def test_scene_too_large_for_lds_tables(rt):
 
 
 def test_stats_account_for_every_stage(rt):
-    """rt_stats: per-kernel times from HIP events, ray and mesh-queue counts; the tail kernel's rays are counted."""
+    """rt_stats: per-kernel times from HIP events (RT_FLAG_STAGE_TIMES), ray and mesh-queue counts; the tail
+    kernel's rays are counted.  Without the flag no stage event is recorded and the times stay 0."""
     o = rt.Options(width=256, height=192, samples=1, seed=4)
     sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    rgb0, ids0, st0 = rt.render(o, sc)
+    assert st0.ms_intersect == 0 and st0.ms_mesh == 0 and st0.ms_shade == 0 and st0.ms_tail == 0 and st0.ms_device > 0
+    o.stage_times = True
     rgb, ids, st = rt.render(o, sc)
+    assert np.array_equal(rgb, rgb0) and np.array_equal(ids, ids0) and st.rays == st0.rays
     ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
     assert st.rays == rst.rays and st.primary_rays == 256 * 192
     assert st.bounce_passes >= 3 and st.n_intersect_launches >= 1

@@ -54,7 +54,7 @@ for accel in ("grid", "kd"):
         print("oracle %.1fs rays %d" % (time.time() - t3, rst.rays), flush=True)
     m = parity.compare(rgb, ids, ref, rids, st.strata)
     print(accel, m, "guards", list(st.guards), list(rst.guards), flush=True)
-    big = rt.Options(width=1920, height=1080, samples=1, seed=2)
+    big = rt.Options(width=1920, height=1080, samples=1, seed=2, stage_times=True)
     dev.render(big, want_ids=False)
     t4 = time.time()
     _, _, bst = dev.render(big, want_ids=False)

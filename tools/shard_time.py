@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 import raytracer_amd as rt
 from raytracer_amd import system
-o = rt.Options(width=3840, height=2160, samples=1, seed=1)
+o = rt.Options(width=3840, height=2160, samples=1, seed=1, stage_times=True)
 scene = rt.parse_file(o, os.path.join(ROOT, "tests/assets/scenes/mesh.scene"), os.path.join(ROOT, "tests/assets"))
 dev = rt.DeviceScene(scene)
 st = torch.cuda.current_stream().cuda_stream
