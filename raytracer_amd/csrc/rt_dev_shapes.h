@@ -670,7 +670,7 @@ RT_CSG_FN bool csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, I
     int sp = 0;
     for (int pc = 0; pc < ob.prog_len; ++pc) {
         int word = sc.prog[ob.prog0 + pc];
-        int op = word >> 24;
+        int op = (word >> 24) & 0x7F;
         if (op == DEV_OP_LEAF) {
             if (sp >= DEV_CSG_STACK) {
                 gd.overflow++;
@@ -682,7 +682,7 @@ RT_CSG_FN bool csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, I
         } else {
             if (sp < 2) return false;
             const bool one_missed = stack[sp - 2].n == 0 || stack[sp - 1].n == 0;
-            if (!csg_apply(op & 0x7F, stack[sp - 2], stack[sp - 1], tmp, gd)) return false;
+            if (!csg_apply(op, stack[sp - 2], stack[sp - 1], tmp, gd)) return false;
             if ((word & DEV_PROG_SKIP) && one_missed && tmp.n > 0) {
                 // csg.rs:33-38,216-221: the surviving operand's end points keep this node's space
                 const DevLeaf &Q = sc.leaves[ob.leaf0 + (word & 0xFFFF)];

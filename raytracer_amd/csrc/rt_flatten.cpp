@@ -420,6 +420,25 @@ struct Flattener {
         return li;
     }
 
+    void check_stack(int idx) const
+    {
+        const int need = stack_need(idx);
+        if (need > DEV_CSG_STACK)
+            throw Err{RT_ERR_UNSUPPORTED, "CSG tree needs " + std::to_string(need) + " interval lists at once (the device keeps " +
+                                              std::to_string(DEV_CSG_STACK) + "): nest the operations on the first operand instead"};
+    }
+
+    // interval lists alive at once while the subtree is evaluated (a, then b, then the operation)
+    int stack_need(int idx, int depth = 0) const
+    {
+        if (depth > 4096) throw Err{RT_ERR_INVALID, "shape tree too deep (or cyclic)"};
+        const rt_shape_node &nd = node(idx);
+        if (nd.kind == RT_SHAPE_MEDIUM) return stack_need(nd.child_a, depth + 1);
+        if (nd.kind != RT_SHAPE_UNION && nd.kind != RT_SHAPE_INTERSECTION && nd.kind != RT_SHAPE_DIFFERENCE) return 1;
+        const int na = stack_need(nd.child_a, depth + 1), nb = stack_need(nd.child_b, depth + 1);
+        return std::max(na, nb + 1);
+    }
+
     // anything that yields intervals: appends to the program (postfix)
     void emit_intervals(int idx, const Mat4 &Wp, const Mat4 &Op, int leaf0)
     {
@@ -457,7 +476,7 @@ struct Flattener {
             }
             int op = nd.kind == RT_SHAPE_UNION ? DEV_OP_UNION
                                                : (nd.kind == RT_SHAPE_INTERSECTION ? DEV_OP_INTERSECTION : DEV_OP_DIFFERENCE);
-            out.prog.push_back(skip_leaf >= 0 ? ((op << 24) | DEV_PROG_SKIP | (skip_leaf - leaf0)) : (op << 24));
+            out.prog.push_back((op << 24) | (skip_leaf >= 0 ? (DEV_PROG_SKIP | (skip_leaf - leaf0)) : 0));
             out.uses_csg = true;
             break;
         }
@@ -774,10 +793,12 @@ struct Flattener {
             frames(root, I, I, W, O);
             obj.frame = push_leaf(DL_NONE, W, O);
             obj.leaf0 = (int)out.leaves.size();
+            check_stack(root.child_a);
             emit_intervals(root.child_a, W, O, obj.leaf0);
             break;
         }
         default: {
+            check_stack(ro.shape);
             emit_intervals(ro.shape, I, I, obj.leaf0);
             bool single = (out.prog.size() - (size_t)obj.prog0) == 1;
             obj.kind = single ? DO_LEAF : DO_CSG;

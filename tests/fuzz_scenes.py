@@ -86,7 +86,7 @@ def _shape(rng, spread, meshes, torus):
     if k == 2:
         inner = _solid(rng, 1, spread, tx=False, torus=False)
         return "homogenous_medium { density %s %s %s }" % (_f(rng.uniform(0.3, 3)), inner, _transform(rng, spread)), True
-    return _solid(rng, 2, spread, torus=torus), False
+    return _solid(rng, 2 if rng.random() < 0.8 else 3, spread, torus=torus), False
 
 
 def scene_text(seed, n_objects=10, meshes=("two_parts.obj", "LinkedTorus.obj"), torus=True, spread=2.2):

@@ -558,6 +558,46 @@ def test_tonemap_kernel_equals_host_pixel_math(rt, tmp_path):
     assert np.abs(img - want).max() <= 1 and np.mean(img != want) < 1e-3
 
 
+def test_nested_csg_chains(rt):
+    """Right-nested chains (`union { a union { b union { c ... } } }`) keep one more interval list alive per level,
+    and a union of n solids in a row can hold n intervals (more: csg.rs:78-79 pushes the interval in hand again).
+    Six levels of unions, a difference and an intersection with such a chain as second operand: within the
+    device's 8 lists of 12 intervals.  Deeper nesting is refused when the scene is created, not miscounted."""
+    def sphere(k):
+        return "sphere { origin <%g, %g, 0> radius 0.45 }" % (0.6 * k - 1.5, 0.15 * (k % 3))
+
+    def chain(op, k, n):
+        return sphere(k) if k == n - 1 else "%s { %s %s }" % (op, sphere(k), chain(op, k + 1, n))
+
+    mat = " material { lambertian texture { solid color white } } }\n"
+    cam = "camera { origin <0, 0, 6> look_at <0, 0, 0> }\n"
+    text = (cam + 'object "u" { ' + chain("union", 0, 7) + mat +
+            'object "d" { difference { cube { <-2, -0.6, -0.4> <2.2, 0.6, 0.4> } ' + chain("union", 0, 6) +
+            " transform { translate <0, 1.6, 0> } }" + mat +
+            'object "i" { intersection { cube { <-2, -0.3, -0.3> <2.2, 0.5, 0.3> } ' + chain("union", 0, 6) +
+            " transform { rotate_z 10 translate <0, -1.6, 0> } }" + mat)
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse(o, text, parity.ASSETS)
+    ro, rd = _random_rays(60000, 31, np.array([0.0, 0.0, 0.0]), 3.0)
+    dev = rt.DeviceScene(sc)
+    got, gst = dev.trace_rays(ro, rd, seed=4)
+    ref, rst = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+    assert gst.interval_overflow == 0
+    for k in range(3):
+        assert (ref["object"] == k).mean() > 0.03
+    assert np.array_equal(got["object"], ref["object"])
+    hit = ref["object"] >= 0
+    assert np.max(np.abs(got["t"][hit] - ref["t"][hit])) < 1e-9
+    assert np.max(np.abs(got["n"][hit] - ref["n"][hit])) < 1e-9
+    deep = rt.parse(o, cam + 'object "b" { ' + chain("union", 0, 10) + mat, parity.ASSETS)
+    with pytest.raises(RuntimeError, match="interval lists at once"):
+        rt.DeviceScene(deep)
+
+    def left(k):        # the same ten solids nested on the first operand need two lists
+        return sphere(0) if k == 0 else "union { %s %s }" % (left(k - 1), sphere(k))
+    rt.DeviceScene(rt.parse(o, cam + 'object "b" { ' + left(9) + mat, parity.ASSETS)).close()
+
+
 def test_reference_known_answers_on_device(rt):
     """The reference's own unit-test vectors, first hit through rt_trace_rays."""
     for case in GOLD["shape_intervals"]:
