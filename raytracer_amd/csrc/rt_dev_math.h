@@ -9,9 +9,11 @@
 // Waves per SIMD the variants of k_intersect are compiled for.  Measured on MI355X (4K csg.scene /
 // 1080p room.scene / 4K x 4 samples fog_light.scene, ms per frame): evaluators out of line at 1 wave
 // 7.8 / 54 / 17.8; inlined at 2 waves 5.1 / 34.2 / 12.7; inlined at 3 waves 5.2 / 31.9 / 11.7; at 4 waves
-// 5.3 / 30.9 / 12.7 (170 spilled registers in the fog variant).  The torus variants gain nothing from 2.
+// 5.3 / 30.9 / 12.7 (170 spilled registers in the fog variant).  The torus variants (the quartic chain stays
+// out of line) run at 2: at 1 the CSG + torus variant took 257 registers and flipped between 3.4 and 5.2 ms per
+// 4K csg.scene frame with unrelated edits; held to 256 it is at 3.3 ms (torus.scene unchanged).
 #ifndef RT_TORUS_WAVES
-#define RT_TORUS_WAVES 1
+#define RT_TORUS_WAVES 2
 #endif
 #ifndef RT_CSG_WAVES
 #define RT_CSG_WAVES 3

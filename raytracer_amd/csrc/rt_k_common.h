@@ -95,10 +95,15 @@ static inline __host__ __device__ uint32_t scene_lds_bytes(const DevScene &sc)
     return b <= RT_SCENE_LDS_MAX ? b : 0u;
 }
 
+// IN_LDS is a compile-time choice on purpose: were the pointers of `v` a run-time choice between memory and
+// LDS, every table access would compile to a flat (address-space-agnostic) load, which waits on both the
+// memory and the LDS counters; unconditionally derived from the LDS array they become ds_read instructions.
+// The launch code picks the IN_LDS = false instantiation for scenes whose tables exceed RT_SCENE_LDS_MAX.
+template <bool IN_LDS>
 RT_DEV DevScene scene_in_lds(const DevScene &sc, unsigned char *lds)
 {
     DevScene v = sc;
-    if (scene_lds_bytes(sc) != 0u) {
+    if (IN_LDS) {
         unsigned char *p = lds;
 #define RT_STAGE(FIELD, TYPE, COUNT)                                                                                   \
     do {                                                                                                               \

@@ -264,13 +264,13 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
     return wants_mesh;
 }
 
-template <bool CSG, bool MEDIUM, bool TORUS>
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS>
 __global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          uint32_t *mesh_queue, uint32_t *mesh_count)
 {
     extern __shared__ double4 scene_lds[];
-    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     __shared__ uint32_t append_lds[RT_BLOCK / 64 + 1];
     const uint32_t count = *count_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;

@@ -153,11 +153,12 @@ RT_DEV bool shade_one(const DevScene &sc, d3 &o, d3 &d, d3 &thr, uint32_t pixel,
     return pp.depth + 1u < pp.max_depth;
 }
 
+template <bool SLDS>
 __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
                                                      RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
 {
     extern __shared__ double4 scene_lds[];
-    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
     const uint32_t count = *count_in_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -223,13 +224,13 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
 // the meshes by brute force across the 64 lanes, the material - with no launch per bounce.
 // The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
-template <bool CSG, bool MEDIUM, bool TORUS>
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS>
 __global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
                                                     uint32_t *lane_totals)
 {
     extern __shared__ double4 scene_lds[];
-    const DevScene sc = scene_in_lds(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     const uint32_t count = counts[pp.depth];
     // a scene with meshes: one wave per path (the 64 lanes share the mesh test); without: one lane per path
     const bool per_lane = !has_mesh;

@@ -315,19 +315,22 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
                             uint32_t *mesh_count, const PassParams &pp, int32_t *ids, hipEvent_t mid)
 {
     dim3 grid(grid_for(live)), block(RT_BLOCK);
-#define LAUNCH_I(C, M, T)                                                                                              \
-    hipLaunchKernelGGL((k_intersect<C, M, T>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, s->hit, pp, ids, s->d_guards, \
+#define LAUNCH_I(C, M, T, L)                                                                                             \
+    hipLaunchKernelGGL((k_intersect<C, M, T, L>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, s->hit, pp, ids, s->d_guards, \
                        s->mesh_queue, mesh_count)
-    const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
+    // scenes whose tables do not fit LDS (scene_lds_bytes == 0) run the one variant that reads them from memory,
+    // which is the most general one
+    const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
     switch (variant) {
-    case 0: LAUNCH_I(false, false, false); break;
-    case 1: LAUNCH_I(false, false, true); break;
-    case 2: LAUNCH_I(false, true, false); break;
-    case 3: LAUNCH_I(false, true, true); break;
-    case 4: LAUNCH_I(true, false, false); break;
-    case 5: LAUNCH_I(true, false, true); break;
-    case 6: LAUNCH_I(true, true, false); break;
-    default: LAUNCH_I(true, true, true); break;
+    case 0: LAUNCH_I(false, false, false, true); break;
+    case 1: LAUNCH_I(false, false, true, true); break;
+    case 2: LAUNCH_I(false, true, false, true); break;
+    case 3: LAUNCH_I(false, true, true, true); break;
+    case 4: LAUNCH_I(true, false, false, true); break;
+    case 5: LAUNCH_I(true, false, true, true); break;
+    case 6: LAUNCH_I(true, true, false, true); break;
+    case 7: LAUNCH_I(true, true, true, true); break;
+    default: LAUNCH_I(true, true, true, false); break;
     }
 #undef LAUNCH_I
     if (mid) (void)hipEventRecord(mid, st);
@@ -369,19 +372,20 @@ static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQue
     uint64_t blocks = ((uint64_t)live * (s->has_mesh ? 64 : 1) + RT_BLOCK - 1) / RT_BLOCK; // wave or lane per path
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-#define LAUNCH_T(C, M, T)                                                                                              \
-    hipLaunchKernelGGL((k_tail<C, M, T>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, s->d_counts,       \
+#define LAUNCH_T(C, M, T, L)                                                                                           \
+    hipLaunchKernelGGL((k_tail<C, M, T, L>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, s->d_counts,       \
                        s->d_counts, d_rgb, pp, s->d_guards, s->has_mesh ? 1 : 0, s->d_counts + 2 * (pp.max_depth + 2))
-    const int variant = (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
+    const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
     switch (variant) {
-    case 0: LAUNCH_T(false, false, false); break;
-    case 1: LAUNCH_T(false, false, true); break;
-    case 2: LAUNCH_T(false, true, false); break;
-    case 3: LAUNCH_T(false, true, true); break;
-    case 4: LAUNCH_T(true, false, false); break;
-    case 5: LAUNCH_T(true, false, true); break;
-    case 6: LAUNCH_T(true, true, false); break;
-    default: LAUNCH_T(true, true, true); break;
+    case 0: LAUNCH_T(false, false, false, true); break;
+    case 1: LAUNCH_T(false, false, true, true); break;
+    case 2: LAUNCH_T(false, true, false, true); break;
+    case 3: LAUNCH_T(false, true, true, true); break;
+    case 4: LAUNCH_T(true, false, false, true); break;
+    case 5: LAUNCH_T(true, false, true, true); break;
+    case 6: LAUNCH_T(true, true, false, true); break;
+    case 7: LAUNCH_T(true, true, true, true); break;
+    default: LAUNCH_T(true, true, true, false); break; // tables in memory: the general variant
     }
 #undef LAUNCH_T
 }
@@ -483,8 +487,12 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                                                               s->d_counts + (opts->max_depth + 2) + depth, pp, ids,
                                                               stage_times ? s->evp[2 + 4 * depth] : nullptr);
                     STAGE_EV(hipEventRecord(s->evp[3 + 4 * depth], st));
-                    hipLaunchKernelGGL(k_shade, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st, s->dev, q_in,
-                                       s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
+                    if (scene_lds_bytes(s->dev) != 0u)
+                        hipLaunchKernelGGL(k_shade<true>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st,
+                                           s->dev, q_in, s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
+                    else
+                        hipLaunchKernelGGL(k_shade<false>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, q_in,
+                                           s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
                     STAGE_EV(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;

@@ -38,8 +38,12 @@ object "floor" { plane { origin <0, 0, 0> normal up } material { lambertian text
 object "bumpy" { mesh { file "bumpy.obj" transform { rotate_x 30 translate <0, 1.1, 0> } } material { metal fuzz 0.05 texture { solid color rgb <0.8, 0.7, 0.5> } } }
 """
 o = rt.Options(width=64, height=48, samples=1, seed=2, max_depth=4)
-for accel in ("grid", "kd"):
-    os.environ["RT_ACCEL"] = accel
+ref = None
+for accel in ("grid", "kd", "auto"):
+    if accel == "auto":
+        os.environ.pop("RT_ACCEL", None)
+    else:
+        os.environ["RT_ACCEL"] = accel
     t0 = time.time()
     sc = rt.parse(o, text, tmp)
     t1 = time.time()
@@ -48,7 +52,7 @@ for accel in ("grid", "kd"):
     rgb, ids, st = dev.render(o)
     print(accel, "tris", sc.desc.contents.n_triangles if hasattr(sc.desc.contents, "n_triangles") else "?",
           "parse %.2fs build %.2fs" % (t1 - t0, t2 - t1), "rays", st.rays, flush=True)
-    if accel == "grid":
+    if ref is None:
         t3 = time.time()
         ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
         print("oracle %.1fs rays %d" % (time.time() - t3, rst.rays), flush=True)
