@@ -113,7 +113,9 @@ __device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, 
 // the near bound of a popped cell is the far bound of the leaf just finished), leaf triangles as
 // contiguous 80-byte records.  Everything around the walk - queue blocks, refill, job records,
 // the merge - is shared.  rt_scene_create picks the structure per scene.
-template <bool KD>
+// JOBS_LDS: every job record is in LDS (at most DEV_MESH_JOBS_LDS of them).  A compile-time fact on purpose:
+// a run-time choice between the LDS copy and memory makes each field access a flat load.
+template <bool KD, bool JOBS_LDS>
 __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
                                                       const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
                                                       uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     }
     __syncthreads();
 // job record `J` (an index): from LDS when it is one of the first DEV_MESH_JOBS_LDS
-#define JOB(J) (*((J) < (int)n_jobs_lds ? (const DevMeshJob *)(jobs_lds + (J)) : (sc.jobs + (J))))
+#define JOB(J) (*((JOBS_LDS || (J) < (int)n_jobs_lds) ? (const DevMeshJob *)(jobs_lds + (J)) : (sc.jobs + (J))))
 
     // every wave takes blocks of 64 queue entries, interleaved with the other waves: neighbouring
     // rays cost about the same, so contiguous chunks would leave whole waves with the expensive ones

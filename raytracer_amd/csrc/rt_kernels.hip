@@ -353,12 +353,22 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             uint64_t mb = ((uint64_t)live + per_wg - 1) / per_wg;
             if (mb < 1) mb = 1;
             if (mb > max_wgs) mb = max_wgs;
-            if (s->mesh_kd)
-                hipLaunchKernelGGL(k_mesh<true>, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_kd_lds_bytes, st, s->dev, q,
-                                   s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp);
-            else
-                hipLaunchKernelGGL(k_mesh<false>, dim3((uint32_t)mb), dim3(RT_MESH_LANES), s->mesh_lds_bytes, st, s->dev, q,
-                                   s->mesh_queue, mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+            const bool jobs_lds = s->dev.n_jobs <= DEV_MESH_JOBS_LDS;
+#define LAUNCH_M(KD, JL, LDS_BYTES)                                                                                    \
+    hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, q, s->mesh_queue,   \
+                       mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
+            if (s->mesh_kd) {
+                if (jobs_lds)
+                    LAUNCH_M(true, true, s->mesh_kd_lds_bytes);
+                else
+                    LAUNCH_M(true, false, s->mesh_kd_lds_bytes);
+            } else {
+                if (jobs_lds)
+                    LAUNCH_M(false, true, s->mesh_lds_bytes);
+                else
+                    LAUNCH_M(false, false, s->mesh_lds_bytes);
+            }
+#undef LAUNCH_M
             walked = 1;
         }
     }
