@@ -12,6 +12,9 @@
 // 5.3 / 30.9 / 12.7 (170 spilled registers in the fog variant).  The torus variants (the quartic chain stays
 // out of line) run at 2: at 1 the CSG + torus variant took 257 registers and flipped between 3.4 and 5.2 ms per
 // 4K csg.scene frame with unrelated edits; held to 256 it is at 3.3 ms (torus.scene unchanged).
+#ifndef RT_PLAIN_WAVES
+#define RT_PLAIN_WAVES 4
+#endif
 #ifndef RT_TORUS_WAVES
 #define RT_TORUS_WAVES 2
 #endif

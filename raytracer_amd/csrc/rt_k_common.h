@@ -36,7 +36,7 @@ struct HitBuf {
 
 // k_intersect streams rays in and hit records out: without CSG it is worth 4 waves per SIMD (a few
 // spilled registers against twice the loads in flight: 1.06 -> 0.87 ms per 4K frame, measured)
-#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(TORUS ? RT_TORUS_WAVES : (CSG ? RT_CSG_WAVES : 4))))
+#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(TORUS ? RT_TORUS_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES))))
 
 struct PassParams {
     uint64_t seed;
