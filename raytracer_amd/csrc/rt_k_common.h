@@ -36,6 +36,11 @@ struct HitBuf {
 
 // k_intersect streams rays in and hit records out: without CSG it is worth 4 waves per SIMD (a few
 // spilled registers against twice the loads in flight: 1.06 -> 0.87 ms per 4K frame, measured)
+#ifndef RT_TAIL_WAVES
+#define RT_TAIL_WAVES 3 // 4K mesh.scene tail 0.36 -> 0.34 ms against 2 (41 spilled registers); cornell_box 0.26 -> 0.27
+#endif
+// k_tail without CSG / fog / torus code (the bench scene's variant): waves per SIMD it is compiled for
+#define RT_TAIL_OCC __attribute__((amdgpu_waves_per_eu((CSG || MEDIUM || TORUS) ? 1 : RT_TAIL_WAVES)))
 #define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(TORUS ? RT_TORUS_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES))))
 
 struct PassParams {

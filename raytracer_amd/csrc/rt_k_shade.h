@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
 // The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
 template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS>
-__global__ void __launch_bounds__(RT_BLOCK) k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
+__global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
                                                     uint32_t *lane_totals)
 {
