@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     uint32_t px_;
                     (void)fetch_ray(sc, q, pp, ri, wo, wd, px_);
                     best_obj = hit.obj[ri];
-                    best_t = best_obj >= 0 ? hit.t[ri] : DBL_MAX;
+                    const double recorded_t = hit.t[ri]; // loaded whatever obj says: one round trip, not two
+                    best_t = best_obj >= 0 ? recorded_t : DBL_MAX;
                     best_aux = 0u;
                     replaced = false;
                     have_ray = true;
