@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--objects", type=int, default=10)
     ap.add_argument("--no-torus", action="store_true")
     ap.add_argument("--dump", default=None)
+    ap.add_argument("--rays", type=int, default=0, help="also trace this many random rays per scene (origins anywhere, also inside solids)")
     a = ap.parse_args()
     lo, _, hi = a.seeds.partition("-")
     seeds = range(int(lo), int(hi or lo) + 1)
@@ -45,9 +46,29 @@ def main():
         m = parity.compare(rgb, ids, ref, rids, st.strata)
         ok = (m["id_match"] >= 0.999 and m["mean_err_255"] <= 1.0 and m["px_close"] >= 0.999
               and list(st.guards) == list(rst.guards) and abs(int(st.rays) - int(rst.rays)) <= max(2, 1e-3 * rst.rays))
+        ray_note = ""
+        if a.rays:
+            rng = np.random.default_rng(1000 + seed)
+            ro = np.array([0.0, 2.2, 0.0]) + rng.normal(size=(a.rays, 3)) * 2.5
+            tg = np.array([0.0, 2.2, 0.0]) + rng.normal(size=(a.rays, 3)) * 1.5
+            rd = tg - ro
+            rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+            dev = rt.DeviceScene(sc)
+            got, gst = dev.trace_rays(ro, rd, seed=seed)
+            want, wst = oracle_lib.trace_rays(sc.desc, ro, rd, seed=seed)
+            dev.close()
+            same = got["object"] == want["object"]
+            hit = same & (want["object"] >= 0)
+            scale = np.maximum(1.0, np.abs(want["t"][hit]))
+            t_ok = float(np.mean(np.abs(got["t"][hit] - want["t"][hit]) / scale < 1e-9)) if hit.any() else 1.0
+            n_ok = float(np.mean(np.all(np.abs(got["n"][hit] - want["n"][hit]) < 1e-7, axis=1))) if hit.any() else 1.0
+            uv_ok = float(np.mean(np.all(np.abs(got["uv"][hit] - want["uv"][hit]) < 1e-6, axis=1))) if hit.any() else 1.0
+            ray_ok = same.mean() >= 0.999 and t_ok >= 0.999 and n_ok >= 0.999 and uv_ok >= 0.995 and list(gst.guards) == list(wst.guards)
+            ray_note = " | rays obj %.5f t %.5f n %.5f uv %.5f guards %s/%s" % (same.mean(), t_ok, n_ok, uv_ok, list(gst.guards), list(wst.guards))
+            ok = ok and ray_ok
         print("seed %3d %s ids %.5f err %.4f close %.5f rays %d/%d guards %s/%s objs %d" % (
             seed, "ok " if ok else "BAD", m["id_match"], m["mean_err_255"], m["px_close"], st.rays, rst.rays,
-            list(st.guards), list(rst.guards), len(np.unique(rids))), flush=True)
+            list(st.guards), list(rst.guards), len(np.unique(rids))) + ray_note, flush=True)
         if not ok:
             bad += 1
             if a.dump:
