@@ -32,6 +32,9 @@ struct HitBuf {
 #ifndef RT_MESH_WAVES
 #define RT_MESH_WAVES 3
 #endif
+#ifndef RT_MESH_MIN_BLOCK
+#define RT_MESH_MIN_BLOCK 4u // fewest lanes a wave of k_mesh uses when the queue is short (480x270 frame: k_mesh 0.39 -> 0.34 ms against 16)
+#endif
 #define RT_MESH_OCC __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, RT_MESH_WAVES)))
 
 // k_intersect streams rays in and hit records out: without CSG it is worth 4 waves per SIMD (a few

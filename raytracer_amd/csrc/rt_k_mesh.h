@@ -151,12 +151,12 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     const uint32_t n_waves = gridDim.x * (RT_MESH_LANES / 64);
     const uint32_t wave = blockIdx.x * (RT_MESH_LANES / 64) + (threadIdx.x >> 6);
     const uint64_t lane_lt = (1ull << lane_id()) - 1ull;
-    // short queues: fewer rays per wave (16 or 32 lanes used), so that the slowest wave of the pass is
+    // short queues: fewer rays per wave (4 to 32 lanes used), so that the slowest wave of the pass is
     // done sooner; the queue length is only known here, the host sized the grid from an upper bound
     uint32_t block = block_arg;
     if (block == 0u) {
         const uint32_t spread = n_waves < resident_waves ? n_waves : resident_waves;
-        block = 16u;
+        block = RT_MESH_MIN_BLOCK;
         while (block < 64u && (uint64_t)block * spread < count) block <<= 1;
     }
     // a wave with a single block has nothing to refill from: it services its lanes twice, to load

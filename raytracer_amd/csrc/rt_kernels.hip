@@ -349,7 +349,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             static const uint32_t refill = getenv("RT_MESH_REFILL") ? (uint32_t)atoi(getenv("RT_MESH_REFILL")) : 16u;
             static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * 6u;
             static const uint32_t block_env = getenv("RT_MESH_BLOCK") ? (uint32_t)atoi(getenv("RT_MESH_BLOCK")) : 0u;
-            const uint64_t per_wg = 16u * (RT_MESH_LANES / 64); // the kernel uses 16, 32 or 64 lanes per wave
+            const uint64_t per_wg = RT_MESH_MIN_BLOCK * (RT_MESH_LANES / 64); // the kernel uses 4 to 64 lanes per wave
             uint64_t mb = ((uint64_t)live + per_wg - 1) / per_wg;
             if (mb < 1) mb = 1;
             if (mb > max_wgs) mb = max_wgs;
