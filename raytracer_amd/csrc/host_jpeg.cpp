@@ -129,6 +129,7 @@ struct Decoder {
         ncomp = u8();
         if (prec != 8) return fail("only 8-bit JPEG samples are supported");
         if (width <= 0 || height <= 0) return fail("bad JPEG dimensions");
+        if ((uint64_t)width * (uint64_t)height > (1ull << 28)) return fail("JPEG image larger than 2^28 pixels");
         if (ncomp != 1 && ncomp != 3) return fail("only greyscale and three-component JPEG files are supported");
         for (int c = 0; c < ncomp; ++c) {
             comp[c].id = u8();
