@@ -84,7 +84,9 @@ RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
     return at;
 }
 
+#ifndef RT_BLOCK_WIDE
 #define RT_BLOCK_WIDE 1024 // ray generation and shading: light on registers, heavy on queue appends
+#endif
 
 // The scene's small tables (objects, leaves, meshes, materials, textures) are read by every ray
 // through chains of dependent loads: objects[k] -> leaves[leaf0] -> parameters.  From memory each
