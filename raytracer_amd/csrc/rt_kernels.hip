@@ -347,7 +347,7 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
             // waves stay and refill their idle lanes from further blocks
             static const uint32_t refill = getenv("RT_MESH_REFILL") ? (uint32_t)atoi(getenv("RT_MESH_REFILL")) : 16u;
-            static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * 6u;
+            static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * 12u; // 4K mesh.scene: 2.09 ms with 256 x 6, 2.04-2.05 with 256 x 12, no trend beyond
             static const uint32_t block_env = getenv("RT_MESH_BLOCK") ? (uint32_t)atoi(getenv("RT_MESH_BLOCK")) : 0u;
             const uint64_t per_wg = RT_MESH_MIN_BLOCK * (RT_MESH_LANES / 64); // the kernel uses 4 to 64 lanes per wave
             uint64_t mb = ((uint64_t)live + per_wg - 1) / per_wg;
