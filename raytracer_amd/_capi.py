@@ -16,6 +16,8 @@ RT_ERR_PARSE = -2
 RT_ERR_IO = -3
 RT_ERR_DEVICE = -4
 RT_ERR_UNSUPPORTED = -5
+RT_NOALLOC_MAX_SLOTS = 104 * 4096
+RT_NOALLOC_MAX_DEPTH = 64
 
 (RT_SHAPE_SPHERE, RT_SHAPE_PLANE, RT_SHAPE_XYRECT, RT_SHAPE_XZRECT, RT_SHAPE_ZYRECT, RT_SHAPE_CUBE,
  RT_SHAPE_CYLINDER, RT_SHAPE_TORUS, RT_SHAPE_UNION, RT_SHAPE_INTERSECTION, RT_SHAPE_DIFFERENCE,
@@ -101,6 +103,8 @@ SIGNATURES = {
                             C.POINTER(rt_stats), rt_progress_cb, C.c_void_p]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p, C.POINTER(rt_stats),
                                    C.c_void_p]),
+    "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p,
+                                           C.POINTER(rt_stats), C.c_void_p]),
     "rt_shard_pixels": (C.c_uint64, [C.POINTER(rt_options)]),
     "rt_shard_map": (C.c_int, [C.POINTER(rt_options), C.POINTER(C.c_uint32)]),
     "rt_unshard_device": (C.c_int, [C.POINTER(rt_options), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -125,6 +129,15 @@ def load(path=None):
         raise ImportError(
             "raytracer_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    # PyTorch-ROCm wheels carry their own libamdhip64.so; librt_amd.so links the one under /opt/rocm.  Whichever
+    # is loaded first serves the whole process, and when it is ours a later `import torch` finds "No HIP GPUs".
+    # A Python process that has torch installed therefore loads torch first (hosts without torch are unaffected).
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

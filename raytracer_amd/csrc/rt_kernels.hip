@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,28 +59,62 @@ static bool rt_debug() { static int v = -1; if (v < 0) v = getenv("RT_DEBUG") ? 
         }                                                                                                              \
     } while (0)
 
+// Wavefront state of one render call: everything the kernels write besides the caller's outputs.
+// Either carved from one hipMalloc that the scene owns and grows on demand, or (rt_render_device_noalloc)
+// from the static device array `rt_noalloc_scratch`.
+struct Workspace {
+    RayQueue q[2];
+    HitBuf hit;
+    uint32_t *mesh_queue = nullptr; // ray indices that need the mesh walk this pass
+    uint32_t *d_counts = nullptr;   // 2 x (depth_cap + 2) + 2: live rays per depth, mesh-queue lengths per depth, k_tail's lane totals
+    uint32_t *d_guards = nullptr;   // 8
+    size_t cap = 0;                 // ray slots
+    uint32_t depth_cap = 0;         // max_depth the counters are sized for
+};
+
+// ---- rt_render_device_noalloc: wavefront state in a static device array -------------------------
+// For callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc).
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends; the name below is only a host-side handle for hipGetSymbolAddress - host code uses the
+// per-device pointer obtained at set-up (rt_scene_create), never the name.
+// RT_NOALLOC_MAX_SLOTS, RT_NOALLOC_MAX_DEPTH: rt_api.h
+#define RT_WS_BYTES_PER_SLOT 216u // carve_workspace: 24 f64 + 6 u32 arrays
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 4096u) // 87.8 MiB
+static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
+#define RT_MAX_DEVICES 64
+static void *g_noalloc_ptr[RT_MAX_DEVICES]; // device address of rt_noalloc_scratch, per device
+
+// once per device, with that device current
+static int noalloc_setup(int device)
+{
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (device < 0 || device >= RT_MAX_DEVICES) return RT_OK; // such a device simply has no no-alloc entry point
+    if (g_noalloc_ptr[device]) return RT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(rt_noalloc_scratch)));
+    g_noalloc_ptr[device] = p;
+    return RT_OK;
+}
+
 struct rt_scene {
     int device = 0;
     std::vector<void *> allocs; // scene data
     DevScene dev;
     // workspace, grown on demand
-    size_t cap = 0;
     void *ws = nullptr;
-    RayQueue q[2];
-    HitBuf hit;
+    Workspace own;
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
     uint64_t n_mesh_tris = 0;
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
     bool mesh_kd = false;           // walk kd-trees instead of grids (chosen in rt_scene_create)
     uint32_t mesh_kd_lds_bytes = 0; // dynamic LDS of k_mesh<KD>: job records + stacks
-    uint32_t *mesh_queue = nullptr; // ray indices that need the mesh walk this pass
-    uint32_t *d_counts = nullptr; // 2 x (max_depth + 2): live rays per depth, then mesh-queue lengths per depth
-    uint32_t counts_cap = 0;
-    uint32_t *d_guards = nullptr; // 6
+    uint32_t host_depth_cap = 0;  // max_depth the pinned buffer and the events below are sized for
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evp; // per-pass timing events: [0] before raygen, then 4 per depth
     std::vector<hipEvent_t> evr; // per depth: its queue length has been copied back
+    std::vector<uint8_t> walked; // per depth: k_mesh (the grid walk) ran
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -94,58 +129,61 @@ template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, co
     return RT_OK;
 }
 
+// Carves the wavefront state for `cap` ray slots and path depths up to `max_depth` out of `base`
+// (256-byte aligned) and returns the bytes used; with base == nullptr it only measures.
+static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Workspace *w)
+{
+    const size_t n = (cap + 63) & ~(size_t)63; // every array starts 256-byte aligned
+    size_t off = 0;
+    auto take = [&](size_t count, size_t elem) {
+        void *r = base ? (void *)(base + off) : nullptr;
+        off += (count * elem + 255) & ~(size_t)255;
+        return r;
+    };
+    Workspace tmp;
+    Workspace &o = w ? *w : tmp;
+    for (int k = 0; k < 2; ++k) {
+        for (int c = 0; c < 3; ++c) o.q[k].o[c] = (double *)take(n, 8);
+        for (int c = 0; c < 3; ++c) o.q[k].d[c] = (double *)take(n, 8);
+        for (int c = 0; c < 3; ++c) o.q[k].thr[c] = (double *)take(n, 8);
+    }
+    o.hit.t = (double *)take(n, 8);
+    for (int c = 0; c < 3; ++c) o.hit.n[c] = (double *)take(n, 8);
+    for (int c = 0; c < 2; ++c) o.hit.uv[c] = (double *)take(n, 8);
+    for (int k = 0; k < 2; ++k) {
+        o.q[k].slot = (uint32_t *)take(n, 4);
+        o.q[k].pixel = (uint32_t *)take(n, 4);
+        o.q[k].primary = 0;
+        o.q[k].row_major = 0;
+        o.q[k].rank = o.q[k].s_i = o.q[k].s_j = 0u;
+        o.q[k].recip_sqrt_spp = 1.0;
+        std::memset(&o.q[k].g, 0, sizeof(o.q[k].g));
+    }
+    o.hit.obj = (int32_t *)take(n, 4);
+    o.mesh_queue = (uint32_t *)take(n, 4);
+    o.d_counts = (uint32_t *)take(2 * ((size_t)max_depth + 2) + 2, 4);
+    o.d_guards = (uint32_t *)take(8, 4);
+    o.cap = cap;
+    o.depth_cap = max_depth;
+    return off;
+}
+
 static void free_workspace(rt_scene *s)
 {
     if (s->ws) (void)hipFree(s->ws);
     s->ws = nullptr;
-    s->cap = 0;
+    s->own = Workspace();
 }
 
-static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
+// pinned read-back words and events for path depths up to max_depth (host side of a render call)
+static int ensure_host_side(rt_scene *s, uint32_t max_depth)
 {
-    if (cap > s->cap) {
-        free_workspace(s);
-        // 2 queues x (9 f64 + 2 u32) + hits (6 f64 + 1 i32), each array 256-B aligned
-        size_t n = (cap + 63) & ~(size_t)63;
-        size_t bytes = n * (2 * (9 * 8 + 2 * 4) + 6 * 8 + 4 + 4);
-        HIP_TRY(hipMalloc(&s->ws, bytes));
-        char *p = (char *)s->ws;
-        auto take = [&](size_t elem) {
-            void *r = p;
-            p += n * elem;
-            return r;
-        };
-        for (int k = 0; k < 2; ++k) {
-            for (int c = 0; c < 3; ++c) s->q[k].o[c] = (double *)take(8);
-            for (int c = 0; c < 3; ++c) s->q[k].d[c] = (double *)take(8);
-            for (int c = 0; c < 3; ++c) s->q[k].thr[c] = (double *)take(8);
-        }
-        s->hit.t = (double *)take(8);
-        for (int c = 0; c < 3; ++c) s->hit.n[c] = (double *)take(8);
-        for (int c = 0; c < 2; ++c) s->hit.uv[c] = (double *)take(8);
-        for (int k = 0; k < 2; ++k) {
-            s->q[k].slot = (uint32_t *)take(4);
-            s->q[k].pixel = (uint32_t *)take(4);
-            s->q[k].primary = 0;
-            s->q[k].row_major = 0;
-            s->q[k].rank = s->q[k].s_i = s->q[k].s_j = 0u;
-            s->q[k].recip_sqrt_spp = 1.0;
-            std::memset(&s->q[k].g, 0, sizeof(s->q[k].g));
-        }
-        s->hit.obj = (int32_t *)take(4);
-        s->mesh_queue = (uint32_t *)take(4);
-        s->cap = cap;
-    }
-    if (max_depth + 2 > s->counts_cap) {
-        if (s->d_counts) (void)hipFree(s->d_counts);
-        s->d_counts = nullptr;
-        HIP_TRY(hipMalloc((void **)&s->d_counts, (2 * (max_depth + 2) + 2) * sizeof(uint32_t))); // + k_tail's lane totals
+    if (max_depth > s->host_depth_cap || !s->h_pinned) {
         if (s->h_pinned) (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
-        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (3 * (max_depth + 2) + 8) * sizeof(uint32_t), hipHostMallocDefault));
-        s->counts_cap = max_depth + 2;
+        HIP_TRY(hipHostMalloc((void **)&s->h_pinned, (3 * ((size_t)max_depth + 2) + 8) * sizeof(uint32_t), hipHostMallocDefault));
+        s->host_depth_cap = max_depth;
     }
-    if (!s->d_guards) HIP_TRY(hipMalloc((void **)&s->d_guards, 8 * sizeof(uint32_t)));
     while (s->evp.size() < 1 + 4 * (size_t)max_depth) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
@@ -160,7 +198,21 @@ static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
         HIP_TRY(hipEventCreate(&s->ev0));
         HIP_TRY(hipEventCreate(&s->ev1));
     }
+    if (s->walked.size() < (size_t)max_depth + 2) s->walked.resize((size_t)max_depth + 2);
     return RT_OK;
+}
+
+static int ensure_workspace(rt_scene *s, size_t cap, uint32_t max_depth)
+{
+    if (cap > s->own.cap || max_depth > s->own.depth_cap || !s->ws) {
+        const size_t want_cap = cap > s->own.cap ? cap : s->own.cap;
+        const uint32_t want_depth = max_depth > s->own.depth_cap ? max_depth : s->own.depth_cap;
+        free_workspace(s);
+        const size_t bytes = carve_workspace(nullptr, want_cap, want_depth, nullptr);
+        HIP_TRY(hipMalloc(&s->ws, bytes));
+        (void)carve_workspace((char *)s->ws, want_cap, want_depth, &s->own);
+    }
+    return ensure_host_side(s, max_depth);
 }
 
 extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
@@ -191,6 +243,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
         rt_scene_destroy(s);
         return code;
     };
+    // set-up for rt_render_device_noalloc: this device's address of the static scratch array, and the
+    // scene's pinned words and events for the deepest path that entry point accepts
+    if ((rc = noalloc_setup(s->device))) return fail(rc);
+    if ((rc = ensure_host_side(s, RT_NOALLOC_MAX_DEPTH))) return fail(rc);
     if ((rc = upload(s, flat.objects, &s->dev.objects))) return fail(rc);
     if ((rc = upload(s, flat.leaves, &s->dev.leaves))) return fail(rc);
     if ((rc = upload(s, flat.prog, &s->dev.prog))) return fail(rc);
@@ -259,8 +315,6 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (!s) return;
     for (void *p : s->allocs) (void)hipFree(p);
     free_workspace(s);
-    if (s->d_counts) (void)hipFree(s->d_counts);
-    if (s->d_guards) (void)hipFree(s->d_guards);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -311,13 +365,13 @@ static int check_options(const rt_options *o)
 
 // nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the mesh pass
 // returns 1 when the grid walk (k_mesh) ran, 0 otherwise; `mid` (if any) is recorded between the two stages
-static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
+static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
                             uint32_t *mesh_count, const PassParams &pp, int32_t *ids, hipEvent_t mid)
 {
     dim3 grid(grid_for(live)), block(RT_BLOCK);
 #define LAUNCH_I(C, M, T, L)                                                                                             \
-    hipLaunchKernelGGL((k_intersect<C, M, T, L>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, s->hit, pp, ids, s->d_guards, \
-                       s->mesh_queue, mesh_count)
+    hipLaunchKernelGGL((k_intersect<C, M, T, L>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, w.hit, pp, ids, w.d_guards, \
+                       w.mesh_queue, mesh_count)
     // scenes whose tables do not fit LDS (scene_lds_bytes == 0) run the one variant that reads them from memory,
     // which is the most general one
     const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
@@ -341,8 +395,8 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
             if (blocks > 256 * 8) blocks = 256 * 8;
             if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), block, 0, st, s->dev, q, s->mesh_queue, mesh_count,
-                               s->hit, ids, pp);
+            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), block, 0, st, s->dev, q, w.mesh_queue, mesh_count,
+                               w.hit, ids, pp);
         } else {
             // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
             // waves stay and refill their idle lanes from further blocks
@@ -355,8 +409,8 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
             if (mb > max_wgs) mb = max_wgs;
             const bool jobs_lds = s->dev.n_jobs <= DEV_MESH_JOBS_LDS;
 #define LAUNCH_M(KD, JL, LDS_BYTES)                                                                                    \
-    hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, q, s->mesh_queue,   \
-                       mesh_count, s->hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
+    hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, q, w.mesh_queue,   \
+                       mesh_count, w.hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
             if (s->mesh_kd) {
                 if (jobs_lds)
                     LAUNCH_M(true, true, s->mesh_kd_lds_bytes);
@@ -377,14 +431,14 @@ static int launch_intersect(rt_scene *s, hipStream_t st, uint32_t live, const Ra
 
 #define RT_TAIL_MAX_TESTS 36000000ull // paths x triangles below which k_tail takes the rest of the stratum (measured)
 
-static void launch_tail(rt_scene *s, hipStream_t st, uint32_t live, const RayQueue &q, const PassParams &pp, double *d_rgb)
+static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q, const PassParams &pp, double *d_rgb)
 {
     uint64_t blocks = ((uint64_t)live * (s->has_mesh ? 64 : 1) + RT_BLOCK - 1) / RT_BLOCK; // wave or lane per path
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
 #define LAUNCH_T(C, M, T, L)                                                                                           \
-    hipLaunchKernelGGL((k_tail<C, M, T, L>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, s->d_counts,       \
-                       s->d_counts, d_rgb, pp, s->d_guards, s->has_mesh ? 1 : 0, s->d_counts + 2 * (pp.max_depth + 2))
+    hipLaunchKernelGGL((k_tail<C, M, T, L>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, w.d_counts,       \
+                       w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, w.d_counts + 2 * (pp.max_depth + 2))
     const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
     switch (variant) {
     case 0: LAUNCH_T(false, false, false, true); break;
@@ -405,8 +459,10 @@ typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
 // the wavefront loop for one shard; d_rgb (sum) and d_ids are in shard layout
 // per-kernel events, recorded only when the caller asked for stage times (RT_FLAG_STAGE_TIMES)
 #define STAGE_EV(CALL) do { if (stage_times) HIP_TRY(CALL); } while (0)
+// `fixed`: a workspace the caller provides (rt_render_device_noalloc); nothing is allocated then, and sizes
+// beyond what it and the scene's host side were set up for are refused.
 static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int32_t *d_ids, rt_stats *stats,
-                         hipStream_t st, stratum_fn per_stratum, void *user)
+                         hipStream_t st, stratum_fn per_stratum, void *user, const Workspace *fixed = nullptr)
 {
     int rc = check_options(opts);
     if (rc) return rc;
@@ -425,8 +481,19 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
     }
     const uint32_t n_slots = (uint32_t)n_slots64;
     RT_TRACE("slots %u", n_slots);
-    rc = ensure_workspace(s, n_slots ? n_slots : 1, opts->max_depth);
-    if (rc) return rc;
+    if (fixed) {
+        if (n_slots > fixed->cap || opts->max_depth > fixed->depth_cap || opts->max_depth > s->host_depth_cap) {
+            rt_host::set_last_error("rt_render_device_noalloc: " + std::to_string(n_slots) + " ray slots, max_depth " +
+                                    std::to_string(opts->max_depth) + " exceed the static scratch buffer (" +
+                                    std::to_string(fixed->cap) + " slots, max_depth " +
+                                    std::to_string(std::min(fixed->depth_cap, s->host_depth_cap)) + ")");
+            return RT_ERR_UNSUPPORTED;
+        }
+    } else {
+        rc = ensure_workspace(s, n_slots ? n_slots : 1, opts->max_depth);
+        if (rc) return rc;
+    }
+    const Workspace &w = fixed ? *fixed : s->own;
     RT_TRACE("workspace ok");
 
     const uint32_t sqrt_spp = (uint32_t)std::sqrt((double)opts->samples); // system.rs:276
@@ -445,7 +512,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
     const size_t n_out = row_major ? (size_t)opts->width * opts->height : (size_t)n_slots;
     HIP_TRY(hipMemsetAsync(d_rgb, 0, n_out * 3 * sizeof(double), st)); // alloc_render_buf
     if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xFF, n_out * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(s->d_guards, 0, 8 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(w.d_guards, 0, 8 * sizeof(uint32_t), st));
     RT_TRACE("memsets queued");
 
     uint32_t done = 0;
@@ -462,9 +529,9 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 hipLaunchKernelGGL(k_fill_background, dim3((n_slots + 255) / 256), dim3(256), 0, st, s->dev, g, rank,
                                    n_slots, d_rgb, row_major ? 1 : 0);
             } else {
-                HIP_TRY(hipMemsetAsync(s->d_counts, 0, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetAsync(w.d_counts, 0, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t), st));
                 // depth 0 reads no ray queue: entry i is slot i and its camera ray is regenerated in place
-                RayQueue q_primary = s->q[0];
+                RayQueue q_primary = w.q[0];
                 q_primary.primary = 1;
                 q_primary.row_major = row_major ? 1 : 0;
                 q_primary.rank = rank;
@@ -472,7 +539,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 q_primary.s_j = s_j;
                 q_primary.g = g;
                 q_primary.recip_sqrt_spp = recip;
-                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_counts, (int)n_slots, 1, st));
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)w.d_counts, (int)n_slots, 1, st));
                 STAGE_EV(hipEventRecord(s->evp[0], st));
                 // `live` bounds the rays of the next pass from above: the newest count that has come
                 // back (counts never grow).  The kernels read the true count on the device; the bound
@@ -487,22 +554,23 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 int cur = 0;
                 uint32_t passes = 0;
                 int tail_at = -1; // depth at which k_tail took over
-                std::vector<uint8_t> walked(opts->max_depth + 1, 0);
+                uint8_t *walked = s->walked.data(); // sized by ensure_host_side
+                std::memset(walked, 0, opts->max_depth + 1);
                 for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
                     pp.depth = depth;
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
                     STAGE_EV(hipEventRecord(s->evp[1 + 4 * depth], st));
-                    const RayQueue &q_in = depth == 0 ? q_primary : s->q[cur];
-                    walked[depth] = (uint8_t)launch_intersect(s, st, live, q_in, s->d_counts + depth,
-                                                              s->d_counts + (opts->max_depth + 2) + depth, pp, ids,
+                    const RayQueue &q_in = depth == 0 ? q_primary : w.q[cur];
+                    walked[depth] = (uint8_t)launch_intersect(s, w, st, live, q_in, w.d_counts + depth,
+                                                              w.d_counts + (opts->max_depth + 2) + depth, pp, ids,
                                                               stage_times ? s->evp[2 + 4 * depth] : nullptr);
                     STAGE_EV(hipEventRecord(s->evp[3 + 4 * depth], st));
                     if (scene_lds_bytes(s->dev) != 0u)
                         hipLaunchKernelGGL(k_shade<true>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st,
-                                           s->dev, q_in, s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
+                                           s->dev, q_in, w.d_counts + depth, w.hit, w.q[1 - cur], w.d_counts + depth + 1, d_rgb, pp);
                     else
                         hipLaunchKernelGGL(k_shade<false>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, q_in,
-                                           s->d_counts + depth, s->hit, s->q[1 - cur], s->d_counts + depth + 1, d_rgb, pp);
+                                           w.d_counts + depth, w.hit, w.q[1 - cur], w.d_counts + depth + 1, d_rgb, pp);
                     STAGE_EV(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;
@@ -511,7 +579,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     // queued across the copy's round trip; near the tail threshold (and on the last
                     // pass) it waits for the newest copy, because the switch needs the count.
                     uint32_t *h_live = s->h_pinned + 2 * (opts->max_depth + 2) + 8;
-                    HIP_TRY(hipMemcpyAsync(h_live + depth + 1, s->d_counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(h_live + depth + 1, w.d_counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipEventRecord(s->evr[depth + 1], st));
                     const bool exact = live <= 8u * tail_max || depth + 1 == opts->max_depth || run_ahead == 0u;
                     int known = exact ? (int)depth + 1 : (int)depth + 1 - (int)run_ahead;
@@ -528,17 +596,16 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                         // few paths left: one launch takes them all to their ends
                         pp.depth = depth + 1;
                         STAGE_EV(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
-                        launch_tail(s, st, live, s->q[cur], pp, d_rgb);
+                        launch_tail(s, w, st, live, w.q[cur], pp, d_rgb);
                         STAGE_EV(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
                         tail_at = (int)depth + 1;
                         break;
                     }
                 }
-                HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_counts, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t),
+                HIP_TRY(hipMemcpyAsync(s->h_pinned, w.d_counts, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, st)); // rays per depth, mesh-queue lengths per depth, lane totals
                 HIP_TRY(hipStreamSynchronize(st));
-                std::vector<uint32_t> mesh_counts(opts->max_depth + 1, 0u);
-                for (uint32_t k = 0; k <= opts->max_depth; ++k) mesh_counts[k] = s->h_pinned[opts->max_depth + 2 + k];
+                const uint32_t *mesh_counts = s->h_pinned + (opts->max_depth + 2);
                 if (rt_debug())
                     for (uint32_t k = 0; k < passes; ++k)
                         RT_TRACE("pass %u: rays %u mesh queue %u", k, s->h_pinned[k], mesh_counts[k]);
@@ -602,7 +669,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
         }
     }
 finished:
-    HIP_TRY(hipMemcpyAsync(s->h_pinned, s->d_guards, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_pinned, w.d_guards, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
@@ -631,6 +698,22 @@ extern "C" int rt_render_device(rt_scene *scene, const rt_options *opts, double 
                                 rt_stats *stats, void *stream)
 {
     return render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, nullptr, nullptr);
+}
+
+extern "C" int rt_render_device_noalloc(rt_scene *scene, const rt_options *opts, double *d_rgb_sum,
+                                        int32_t *d_primary_ids, rt_stats *stats, void *stream)
+{
+    if (!scene) {
+        rt_host::set_last_error("rt_render_device_noalloc: null scene");
+        return RT_ERR_INVALID;
+    }
+    void *base = (scene->device >= 0 && scene->device < RT_MAX_DEVICES) ? g_noalloc_ptr[scene->device] : nullptr;
+    Workspace w;
+    if (!base || carve_workspace((char *)base, RT_NOALLOC_MAX_SLOTS, RT_NOALLOC_MAX_DEPTH, &w) > RT_NOALLOC_BYTES) {
+        rt_host::set_last_error("rt_render_device_noalloc: no static scratch buffer on this device");
+        return RT_ERR_DEVICE;
+    }
+    return render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, nullptr, nullptr, &w);
 }
 
 extern "C" int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, const double *d_shard_rgb,
@@ -755,19 +838,20 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_workspace(s, (size_t)n, 1);
     if (rc) return rc;
+    const Workspace &w = s->own;
     // de-interleave on the host into the SoA queue
     std::vector<double> col(n);
     for (int c = 0; c < 3; ++c) {
         for (uint64_t i = 0; i < n; ++i) col[i] = origins[3 * i + c];
-        HIP_TRY(hipMemcpy(s->q[0].o[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.q[0].o[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
         for (uint64_t i = 0; i < n; ++i) col[i] = directions[3 * i + c];
-        HIP_TRY(hipMemcpy(s->q[0].d[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.q[0].d[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
     uint32_t n32 = (uint32_t)n;
-    hipLaunchKernelGGL(k_iota, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, s->q[0].slot, s->q[0].pixel,
-                       s->q[0].thr[0], s->q[0].thr[1], s->q[0].thr[2]);
-    HIP_TRY(hipMemcpy(s->d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(s->d_guards, 0, 8 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_iota, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, w.q[0].slot, w.q[0].pixel,
+                       w.q[0].thr[0], w.q[0].thr[1], w.q[0].thr[2]);
+    HIP_TRY(hipMemcpy(w.d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(w.d_guards, 0, 8 * sizeof(uint32_t)));
     PassParams pp;
     pp.seed = seed;
     pp.stratum = 0;
@@ -775,18 +859,18 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     pp.max_depth = 1;
     pp.force_uv = 1;
     pp.bias = 0.0;
-    HIP_TRY(hipMemset(s->d_counts + 3, 0, sizeof(uint32_t)));
-    (void)launch_intersect(s, nullptr, n32, s->q[0], s->d_counts, s->d_counts + 3, pp, nullptr, nullptr);
+    HIP_TRY(hipMemset(w.d_counts + 3, 0, sizeof(uint32_t)));
+    (void)launch_intersect(s, w, nullptr, n32, w.q[0], w.d_counts, w.d_counts + 3, pp, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<int32_t> obj(n);
     std::vector<double> cols[6];
-    double *src[6] = {s->hit.t, s->hit.n[0], s->hit.n[1], s->hit.n[2], s->hit.uv[0], s->hit.uv[1]};
+    double *src[6] = {w.hit.t, w.hit.n[0], w.hit.n[1], w.hit.n[2], w.hit.uv[0], w.hit.uv[1]};
     for (int c = 0; c < 6; ++c) {
         cols[c].resize(n);
         HIP_TRY(hipMemcpy(cols[c].data(), src[c], n * sizeof(double), hipMemcpyDeviceToHost));
     }
-    HIP_TRY(hipMemcpy(obj.data(), s->hit.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(obj.data(), w.hit.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
         hits[i].t = cols[0][i];
         hits[i].n[0] = cols[1][i];
@@ -800,7 +884,7 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         uint32_t g[6];
-        HIP_TRY(hipMemcpy(g, s->d_guards, sizeof(g), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(g, w.d_guards, sizeof(g), hipMemcpyDeviceToHost));
         stats->rays = n;
         for (int k = 0; k < 5; ++k) stats->guards[k] = g[k];
         stats->interval_overflow = g[5];

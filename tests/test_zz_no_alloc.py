@@ -1,0 +1,52 @@
+"""rt_render_device_noalloc: the allocation-free variant of rt_render_device (wavefront state in a static
+device array of the library).  Same outputs, bit for bit, on two calls in a row, the second smaller (the
+array keeps the first call's contents); sizes beyond the array are refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard(rt, dev, o, noalloc, rank=0, count=1):
+    import torch
+    from raytracer_amd import _capi, system
+    n = system.shard_pixels(o, rank, count)
+    buf = torch.full((n * 3,), 7.0, dtype=torch.float64, device="cuda")
+    ids = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    oc = o.to_c(rank, count)
+    st = _capi.rt_stats()
+    fn = rt.lib.rt_render_device_noalloc if noalloc else rt.lib.rt_render_device
+    rc = fn(dev._h, C.byref(oc), C.c_void_p(buf.data_ptr()), C.c_void_p(ids.data_ptr()), C.byref(st),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return rc, buf.cpu().numpy(), ids.cpu().numpy(), st
+
+
+def test_noalloc_equals_render_device(rt):
+    from raytracer_amd import _capi
+    scenes = {}
+    # first call: close to the limit; second: a smaller shard of another scene (CSG + torus variant)
+    for name, w, h, samples, seed, rank, count in (("mesh", 640, 480, 4, 5, 0, 1), ("csg", 200, 150, 1, 9, 1, 3),
+                                                   ("fog_light", 96, 64, 4, 2, 0, 1)):
+        o = rt.Options(width=w, height=h, samples=samples, seed=seed)
+        sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+        dev = rt.DeviceScene(sc)
+        scenes[name] = dev
+        rc, rgb, ids, st = _shard(rt, dev, o, True, rank, count)
+        assert rc == 0, rt.lib.rt_last_error()
+        rc2, rgb2, ids2, st2 = _shard(rt, dev, o, False, rank, count)
+        assert rc2 == 0
+        assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2)
+        assert st.rays == st2.rays and st.rays > 0 and list(st.guards) == list(st2.guards)
+    # beyond the static array: refused with a clear error, nothing rendered
+    o = rt.Options(width=1024, height=768, samples=1, seed=1)
+    rc, rgb, ids, st = _shard(rt, scenes["mesh"], o, True)
+    assert rc == _capi.RT_ERR_UNSUPPORTED and b"static scratch" in rt.lib.rt_last_error()
+    assert (rgb == 7.0).all()
+    o = rt.Options(width=64, height=64, samples=1, seed=1, max_depth=_capi.RT_NOALLOC_MAX_DEPTH + 1)
+    rc, rgb, ids, st = _shard(rt, scenes["mesh"], o, True)
+    assert rc == _capi.RT_ERR_UNSUPPORTED
