@@ -1952,6 +1952,60 @@ int oracle_render_rows(const rt_scene_desc *desc, const rt_options *opts, uint32
     return RT_OK;
 }
 
+// Rows [y0, y1) of every stratum of a frame, at the frame's full geometry, summed in stratum order
+// (render_sample + combine_renderbuf, system.rs:244-261,284-299, restricted to a band): lets a test check a
+// band of a multi-sample 8K frame.  ids: primary hits of stratum 0.
+int oracle_render_rows_strata(const rt_scene_desc *desc, const rt_options *opts, uint32_t y0, uint32_t y1, int threads,
+                              double *rgb_sum, int32_t *ids, rt_stats *stats)
+{
+    if (!desc || !opts || !rgb_sum || y0 >= y1 || y1 > opts->height) return RT_ERR_INVALID;
+    std::unique_ptr<Scene> scene;
+    try {
+        scene = build_scene(desc, opts->width, opts->height);
+    } catch (const std::exception &) {
+        return RT_ERR_INVALID;
+    }
+    RenderContext ctx;
+    ctx.options = Options{opts->width, opts->height, opts->bias, (uint16_t)opts->max_depth, opts->samples};
+    ctx.scene = scene.get();
+    ctx.sqrt_spp = (uint32_t)std::sqrt((double)opts->samples);
+    ctx.recip_sqrt_spp = 1.0 / std::sqrt((double)opts->samples);
+    const uint32_t W = opts->width;
+    const size_t n_values = (size_t)(y1 - y0) * W * 3;
+    std::vector<double> tmp(n_values);
+    std::fill(rgb_sum, rgb_sum + n_values, 0.0);
+    double *base = tmp.data() - (size_t)y0 * W * 3; // render_rows indexes by absolute row
+    int32_t *ibase = ids ? ids - (size_t)y0 * W : nullptr;
+    Totals totals;
+    if (threads < 1) threads = 1;
+    for (uint32_t s_i = 0; s_i < ctx.sqrt_spp; ++s_i) {
+        for (uint32_t s_j = 0; s_j < ctx.sqrt_spp; ++s_j) {
+            std::atomic<uint32_t> next_row{y0};
+            const bool first = s_i == 0 && s_j == 0;
+            auto worker = [&]() {
+                for (;;) {
+                    uint32_t y = next_row.fetch_add(1);
+                    if (y >= y1) break;
+                    render_rows(ctx, opts->seed, base, first ? ibase : nullptr, s_i, s_j, y, y + 1);
+                }
+                totals.flush();
+            };
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+            for (auto &t : pool) t.join();
+            for (size_t k = 0; k < n_values; ++k) rgb_sum[k] += tmp[k]; // combine_renderbuf
+        }
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays = totals.rays;
+        stats->strata = ctx.sqrt_spp * ctx.sqrt_spp;
+        stats->primary_rays = (uint64_t)(y1 - y0) * W * stats->strata;
+        for (int k = 0; k < 5; ++k) stats->guards[k] = totals.guards[k];
+    }
+    return RT_OK;
+}
+
 // Ray::trace for a batch of rays (ray i: pixel i, stratum 0, depth 0).
 int oracle_trace_rays(const rt_scene_desc *desc, uint64_t seed, uint64_t n, const double *origins,
                       const double *directions, rt_hit *hits, rt_stats *stats)

@@ -32,6 +32,8 @@ def lib():
         L.oracle_render_rows.restype = C.c_int
         L.oracle_render_rows.argtypes = [C.POINTER(_capi.rt_scene_desc), C.POINTER(_capi.rt_options), C.c_uint32,
                                          C.c_uint32, C.c_int, dp, C.POINTER(C.c_int32), C.POINTER(_capi.rt_stats)]
+        L.oracle_render_rows_strata.restype = C.c_int
+        L.oracle_render_rows_strata.argtypes = L.oracle_render_rows.argtypes
         L.oracle_trace_rays.restype = C.c_int
         L.oracle_trace_rays.argtypes = [C.POINTER(_capi.rt_scene_desc), C.c_uint64, C.c_uint64, dp, dp,
                                         C.POINTER(_capi.rt_hit), C.POINTER(_capi.rt_stats)]
@@ -95,6 +97,19 @@ def render_rows(desc_ptr, opts, y0, y1, threads=1):
                                   ids.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(stats))
     if rc != 0:
         raise RuntimeError("oracle_render_rows failed: %d" % rc)
+    return rgb, ids, stats
+
+
+def render_rows_strata(desc_ptr, opts, y0, y1, threads=1):
+    """rows [y0, y1) of every stratum, summed in stratum order -> (rgb_sum [y1-y0, W, 3], ids of stratum 0, stats)"""
+    W = opts.width
+    rgb = np.zeros((y1 - y0, W, 3), dtype=np.float64)
+    ids = np.full((y1 - y0, W), -2, dtype=np.int32)
+    stats = _capi.rt_stats()
+    rc = lib().oracle_render_rows_strata(desc_ptr, C.byref(opts), y0, y1, int(threads), _dp(rgb),
+                                         ids.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(stats))
+    if rc != 0:
+        raise RuntimeError("oracle_render_rows_strata failed: %d" % rc)
     return rgb, ids, stats
 
 

@@ -274,6 +274,64 @@ def test_full_size_band_mesh_4k(rt):
     assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2) and st.rays == st2.rays
 
 
+def _render_sharded(dev, o, count):
+    """The frame as `count` tile shards rendered one after the other on this GPU (as `count` GPUs would render
+    them), scattered into the row-major image with rt_unshard_device -> (rgb [H,W,3], ids [H,W], rays)."""
+    import torch
+    from raytracer_amd import system
+    H, W = o.height, o.width
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    fids = torch.full((H * W,), -5, dtype=torch.int32, device="cuda")
+    n_max = max(system.shard_pixels(o, r, count) for r in range(count))
+    buf = torch.zeros(n_max * 3, dtype=torch.float64, device="cuda")
+    ibuf = torch.zeros(n_max, dtype=torch.int32, device="cuda")
+    rays = 0
+    for r in range(count):
+        st = dev.render_shard(o, r, count, buf.data_ptr(), ibuf.data_ptr(), stream)
+        rays += st.rays
+        system.unshard(o, r, count, buf.data_ptr(), full.data_ptr(), ibuf.data_ptr(), fids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    return full.cpu().numpy().reshape(H, W, 3), fids.cpu().numpy().reshape(H, W), rays
+
+
+# BASELINE.json configs[1..4] at their full sizes: (scene, width, height, samples, first row of the band, rows,
+# compare the whole frame's ray count with the oracle's, also render as 8 shards)
+FULL_SIZE = [("cornell_box", 1920, 1080, 1, 500, 24, True, False),
+             ("mesh", 3840, 2160, 1, 1000, 24, True, True),
+             ("torus", 3840, 2160, 1, 1068, 24, True, False),
+             ("csg", 3840, 2160, 1, 1068, 24, True, False),
+             ("fog_light", 7680, 4320, 16, 2600, 16, False, True)]
+
+
+@pytest.mark.parametrize("name,w,h,samples,y0,rows,count_rays,sharded", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
+def test_full_size_band(rt, name, w, h, samples, y0, rows, count_rays, sharded):
+    """Every BASELINE configuration at its full size (system.rs:244-253,276-286): a band of rows, all strata
+    summed, against the oracle (ids, tone-mapped error, every pixel to 1e-9); the whole frame's ray count
+    against the oracle's where the oracle finishes the frame in seconds (not 8K x 16: there the per-pixel
+    agreement to 1e-9 of the band is what says that the paths are the same); the frame rendered as 8 tile
+    shards equal to the unsharded frame, bit for bit (8K x 16 = 33 M slots: slot and offset arithmetic)."""
+    o = rt.Options(width=w, height=h, samples=samples, seed=1)
+    sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+    dev = rt.DeviceScene(sc)
+    rgb, ids, st = dev.render(o)
+    assert st.strata == samples and st.primary_rays == w * h * samples
+    assert np.isfinite(rgb).all() and (rgb >= 0).all()
+    y1 = y0 + rows
+    ref, rids, rst = oracle_lib.render_rows_strata(sc.desc, o.to_c(), y0, y1, threads=16)
+    m = parity.compare(rgb[y0:y1], ids[y0:y1], ref, rids, st.strata)
+    assert m["id_match"] >= ID_MATCH_MIN and m["mean_err_255"] <= MEAN_ERR_MAX and m["px_close"] >= CLOSE_MIN, m
+    assert len(np.unique(rids)) >= 2                       # the band crosses geometry, not only background
+    assert st.interval_overflow == 0
+    if count_rays:
+        _, _, fst = oracle_lib.render(sc.desc, o.to_c(), threads=16, want_ids=False)
+        assert abs(int(st.rays) - int(fst.rays)) <= 1e-3 * fst.rays, (st.rays, fst.rays)
+        assert list(st.guards) == list(fst.guards)
+    if sharded:
+        srgb, sids, srays = _render_sharded(dev, o, 8)
+        assert np.array_equal(srgb, rgb) and np.array_equal(sids, ids) and srays == st.rays
+
+
 def test_sharded_render_equals_whole(rt):
     """Tiles rendered as 3 shards (as 3 GPUs would) reassemble to the single-GPU frame, bit for bit."""
     import torch
