@@ -2234,6 +2234,46 @@ void oracle_camera_ray(double width, double height, double fov, const double *or
     out_ray[5] = r.direction.z;
 }
 
+// dielectric.rs:68-108 and texture.rs:54-94 on their own, for the analytic checks in tests/test_analytic.py
+double oracle_fresnel(const double *incident, const double *normal, double ior)
+{
+    return fresnel(dir(incident[0], incident[1], incident[2]), dir(normal[0], normal[1], normal[2]), ior);
+}
+
+void oracle_refract(const double *incident, const double *normal, double ior, double *out)
+{
+    Direction r = refract(dir(incident[0], incident[1], incident[2]), dir(normal[0], normal[1], normal[2]), ior);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+}
+
+void oracle_reflect(const double *incident, const double *normal, double *out)
+{
+    Direction r = reflect(dir(incident[0], incident[1], incident[2]), dir(normal[0], normal[1], normal[2]));
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+}
+
+// kind: RT_TEX_*; pixels: RGB8 rows top to bottom (RT_TEX_IMAGE only)
+void oracle_texture_color(int kind, const double *c1, const double *c2, double scale, uint32_t width, uint32_t height,
+                          const uint8_t *pixels, double u, double v, double *out)
+{
+    Texture t;
+    t.kind = kind;
+    t.c1 = Color{c1[0], c1[1], c1[2]};
+    t.c2 = Color{c2[0], c2[1], c2[2]};
+    t.scale = scale;
+    t.width = width;
+    t.height = height;
+    t.pixels = pixels;
+    Color c = t.color_at_uv(Vector2f{u, v});
+    out[0] = c.r;
+    out[1] = c.g;
+    out[2] = c.b;
+}
+
 // Philox block for the known-answer vectors
 void oracle_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out)
 {

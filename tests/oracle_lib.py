@@ -60,6 +60,15 @@ def lib():
         L.oracle_shape_intersect.argtypes = [C.POINTER(_capi.rt_scene_desc), C.c_int, dp, dp, dp]
         L.oracle_camera_ray.restype = None
         L.oracle_camera_ray.argtypes = [C.c_double, C.c_double, C.c_double, dp, dp, C.c_double, C.c_double, dp, dp, dp]
+        L.oracle_fresnel.restype = C.c_double
+        L.oracle_fresnel.argtypes = [dp, dp, C.c_double]
+        L.oracle_refract.restype = None
+        L.oracle_refract.argtypes = [dp, dp, C.c_double, dp]
+        L.oracle_reflect.restype = None
+        L.oracle_reflect.argtypes = [dp, dp, dp]
+        L.oracle_texture_color.restype = None
+        L.oracle_texture_color.argtypes = [C.c_int, dp, dp, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8),
+                                           C.c_double, C.c_double, dp]
         L.oracle_philox.restype = None
         L.oracle_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
         _lib = L
@@ -150,3 +159,33 @@ def shape_intersect(desc_ptr, node, o, d):
     out = np.zeros(6, dtype=np.float64)
     rc = lib().oracle_shape_intersect(desc_ptr, node, _dp(arr(*o)), _dp(arr(*d)), _dp(out))
     return rc, out
+
+
+def fresnel(incident, normal, ior):
+    return float(lib().oracle_fresnel(_dp(arr(*incident)), _dp(arr(*normal)), float(ior)))
+
+
+def refract(incident, normal, ior):
+    out = np.zeros(3)
+    lib().oracle_refract(_dp(arr(*incident)), _dp(arr(*normal)), float(ior), _dp(out))
+    return out
+
+
+def reflect(incident, normal):
+    out = np.zeros(3)
+    lib().oracle_reflect(_dp(arr(*incident)), _dp(arr(*normal)), _dp(out))
+    return out
+
+
+def texture_color(kind, u, v, c1=(0, 0, 0), c2=(0, 0, 0), scale=1.0, image=None):
+    """image: (H, W, 3) uint8 for RT_TEX_IMAGE"""
+    out = np.zeros(3)
+    if image is not None:
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = img.shape[:2]
+        px = img.ctypes.data_as(C.POINTER(C.c_uint8))
+    else:
+        h = w = 0
+        px = None
+    lib().oracle_texture_color(int(kind), _dp(arr(*c1)), _dp(arr(*c2)), float(scale), w, h, px, float(u), float(v), _dp(out))
+    return out

@@ -705,3 +705,17 @@ def test_edge_cases(rt):
     got, gst = dev.trace_rays(ro, rd)
     ref, rst = oracle_lib.trace_rays(sc.desc, ro, rd)
     assert list(got["object"]) == list(ref["object"]) and list(gst.guards) == list(rst.guards)
+
+
+@pytest.mark.parametrize("case", ["test_transformed_sphere_closed_form", "test_transformed_cylinder_closed_form",
+                                  "test_transformed_cube_and_rects", "test_csg_first_hit_by_point_classification",
+                                  "test_mesh_scene_against_brute_force_moller_trumbore", "test_fog_free_path_statistics"])
+def test_analytic_cases_on_device(rt, case):
+    """The numpy-only expectations of tests/test_analytic.py (closed-form quadrics, CSG by point classification,
+    brute-force triangles, Beer-Lambert) against the device's rt_trace_rays instead of the oracle."""
+    import test_analytic
+    test_analytic.ON_DEVICE[0] = True
+    try:
+        getattr(test_analytic, case)(rt)
+    finally:
+        test_analytic.ON_DEVICE[0] = False
