@@ -14,7 +14,8 @@ value = rays traced by all ranks in the K timed steps / max-over-ranks time.
 Extra objects on the JSON line (see DESIGN.md "Measurement"):
   roofline      the dominant kernel by GPU time (k_mesh, the grid walk of the rays queued for
                 the mesh): algorithmic bytes per queued ray / its HIP-event time; the other
-                kernels of the frame are listed under "kernels" the same way
+                kernels of the frame are listed under "kernels" the same way (k_intersect: nearest
+                analytic hit + shading of the rays with no mesh to visit; k_shade: the mesh records)
   frame_hbm     SURVEY 8(d)'s whole-frame figure: (264 B/ray + 24 B/pixel-sample) / frame time
   cpu_baseline  the CPU oracle (a restatement of the reference, `kind: port`) on a
                 bounded sample of the same scene; N=1, rank 0 only
@@ -31,24 +32,69 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SAMPLES = 3840, 2160, 1
 SCENE = "mesh"
-BYTES_PER_RAY_INTERSECT = 52 + 52   # origin, direction, pixel read + hit record written
-BYTES_PER_RAY_MESH = 4 + 48 + 12 + 52  # queue entry, origin + direction, recorded hit (t, object) read; hit record written
-BYTES_PER_RAY_SHADE = 80 + 52 + 80  # ray + hit read, scattered ray written (or 24 B of frame buffer updated)
+BYTES_PER_RAY_INTERSECT = 80 + 80   # ray record read; scattered ray written (or a 132 B mesh record, or 24 B of frame buffer)
+BYTES_PER_RAY_MESH = 48 + 12 + 52   # mesh record by position: origin + direction, recorded hit (t, object) read; hit record written
+BYTES_PER_RAY_SHADE = 132 + 80      # mesh record (ray + hit) read, scattered ray written (or 24 B of frame buffer updated)
 BYTES_PER_RAY_FRAME = 2 * 80 + 2 * 52
 BYTES_PER_PIXEL_SAMPLE = 24
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(scene):
-    """Time the oracle on the host cores on a bounded sample of the bench workload:
-    the whole 4K frame row-parallel over all cores (reported as cpu_baseline) and a
-    1/16-size frame on one thread = the reference's own threading at samples=1."""
+def kernel_sources_sha():
+    """Fingerprint of the device code (every file under raytracer_amd/csrc and include/)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "raytracer_amd", "csrc"), os.path.join(ROOT, "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".h", ".hip", ".cpp")):
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def host_cores():
+    """Threads for the all-cores leg, and what the machine shows.  A one-GPU lease of the GPU box owns a share of the
+    host (the harness exports it as OMP_NUM_THREADS = 16); os.cpu_count() shows the whole machine there."""
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = visible
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or affinity
+    return min(share, affinity), {"cpus_visible": visible, "affinity": affinity,
+                                   "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
+
+
+def native_oracle():
+    """Rebuild the oracle here with -march=native (the reference's target-cpu=native); falls back to the shipped
+    x86-64-v3 build when no compiler is at hand."""
+    import shutil
+    import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
+    odir = os.path.join(ROOT, "oracle")
+    if shutil.which("g++") and shutil.which("make"):
+        try:
+            subprocess.check_call(["make", "-s", "-B", "-C", odir, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  timeout=240)
+            oracle_lib.use_library(os.path.join(odir, "liboracle_native.so"))
+            return oracle_lib, "g++ -O3 -march=native -flto, built on this host"
+        except Exception as e:  # noqa: BLE001
+            note = "native build failed (%s); " % type(e).__name__
+    else:
+        note = "no g++ on this host; "
+    return oracle_lib, note + "shipped build, g++ -O3 -march=x86-64-v3 -flto"
+
+
+def cpu_baseline(scene):
+    """Time the oracle on the host cores on a bounded sample of the bench workload:
+    the whole 4K frame row-parallel over this lease's cores (reported as cpu_baseline) and a
+    1/16-size frame on one thread = the reference's own threading at samples=1."""
+    oracle_lib, build_note = native_oracle()
     import raytracer_amd as rt
     path = os.path.join(ROOT, "tests", "assets", "scenes", scene + ".scene")
     assets = os.path.join(ROOT, "tests", "assets")
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    cores, seen = host_cores()
     w, h = WIDTH, HEIGHT
     o = rt.Options(width=w, height=h, samples=SAMPLES, seed=1)
     sc = rt.parse_file(o, path, assets)
@@ -61,9 +107,11 @@ def cpu_baseline(scene):
     t0 = time.perf_counter()
     _, _, st1 = oracle_lib.render(sc1.desc, o1.to_c(), threads=1, want_ids=False)
     t_one = time.perf_counter() - t0
-    return ({"value": st.rays / t_all / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-             "sample": "%s.scene %dx%d samples=%d seed=1 (one whole bench frame, %d rays), oracle/liboracle.so "
-                       "row-parallel over %d threads, %.1f s" % (scene, w, h, SAMPLES, st.rays, cores, t_all)},
+    return ({"value": st.rays / t_all / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "host": seen,
+             "build": build_note,
+             "sample": "%s.scene %dx%d samples=%d seed=1 (one whole bench frame, %d rays), oracle row-parallel over %d "
+                       "threads = every core of this lease (the machine shows %d CPUs, the lease's share is %d), %.1f s"
+                       % (scene, w, h, SAMPLES, st.rays, cores, seen["cpus_visible"], cores, t_all)},
             {"value": st1.rays / t_one / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
              "sample": "%s.scene %dx%d samples=%d seed=1, one thread (the reference parallelises over strata only), %.1f s"
                        % (scene, w1, h1, SAMPLES, t_one)})
@@ -157,7 +205,7 @@ def main():
     t0 = time.perf_counter()
     rays = 0
     acc = dict(ms_int=0.0, ms_mesh=0.0, ms_shade=0.0, ms_tail=0.0, ms_raygen=0.0, n_int=0, n_mesh=0, int_rays=0,
-               mesh_rays=0)
+               mesh_rays=0, mesh_records=0)
     for k in range(args.steps):
         st = step(args.warmup + k)
         rays += st.rays
@@ -170,6 +218,7 @@ def main():
         acc["n_mesh"] += st.n_mesh_launches
         acc["int_rays"] += st.intersect_rays
         acc["mesh_rays"] += st.mesh_rays
+        acc["mesh_records"] += st.mesh_records
     barrier()
     dt = time.perf_counter() - t0
     opts.stage_times = False
@@ -205,17 +254,26 @@ def main():
                     "launches": launches, "ms_per_step": ms / args.steps}
         kernels = [line("k_mesh", acc["mesh_rays"], BYTES_PER_RAY_MESH, acc["ms_mesh"], acc["n_mesh"]),
                    line("k_intersect", acc["int_rays"], BYTES_PER_RAY_INTERSECT, acc["ms_int"], acc["n_int"]),
-                   line("k_shade", acc["int_rays"], BYTES_PER_RAY_SHADE, acc["ms_shade"], acc["n_int"])]
-        traffic = None
+                   line("k_shade", acc["mesh_records"], BYTES_PER_RAY_SHADE, acc["ms_shade"], acc["n_int"])]
+        # HBM bytes per k_mesh launch from the PMC passes over this same command (tools/pmc.sh, tools/traffic.py).
+        # The file records the kernel sources it was measured on; after any change to them the figure is
+        # withheld (null) rather than quoted stale.
+        traffic, traffic_note = None, "no PMC measurement committed"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("k_mesh_hbm_bytes_per_launch")
+                    tj = json.load(f)
+                if tj.get("sources_sha256") == kernel_sources_sha():
+                    traffic = tj.get("k_mesh_hbm_bytes_per_launch")
+                    traffic_note = "profiles/traffic.json, measured on these kernel sources"
+                else:
+                    traffic_note = "profiles/traffic.json was measured on other kernel sources: withheld"
             except Exception:
                 traffic = None
         roof = dict(kernels[0])
         roof["traffic"] = traffic
+        roof["traffic_source"] = traffic_note
         roof["note"] = ("ms_mesh is the k_mesh + k_mesh_brute stage; k_mesh is a latency-bound grid walk, its HBM "
                         "fraction is low by construction (DESIGN.md)")
         frame_bytes = rays_total * BYTES_PER_RAY_FRAME + args.width * args.height * args.samples * BYTES_PER_PIXEL_SAMPLE * args.steps

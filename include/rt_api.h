@@ -194,14 +194,16 @@ typedef struct rt_stats {
     double ms_device;           /* GPU time of the call, HIP events on its stream */
     /* per-kernel GPU time, HIP events on the same stream, summed over launches */
     double ms_raygen;
-    double ms_intersect; /* k_intersect: every object except the triangles      */
-    double ms_shade;
+    double ms_intersect; /* k_intersect: nearest hit over every object except the triangles, and the
+                          * shading of the rays that have no mesh to visit                            */
+    double ms_shade;     /* k_shade: the shading of the rays that went through the mesh record queue  */
     double ms_mesh;      /* k_mesh / k_mesh_brute: the rays queued for a mesh   */
     double ms_tail;      /* k_tail: the last few paths, all remaining bounces   */
     uint32_t n_intersect_launches; /* k_intersect launches that had rays        */
     uint32_t n_mesh_launches;      /* k_mesh (grid walk) launches               */
     uint64_t mesh_rays;            /* rays those k_mesh launches walked         */
     uint64_t intersect_rays;       /* rays those k_intersect launches took      */
+    uint64_t mesh_records;         /* rays that went through the mesh record queue (k_mesh or k_mesh_brute, then k_shade) */
 } rt_stats;
 
 /* Nearest-hit record, one per ray: RayHit (system.rs:154-171). */

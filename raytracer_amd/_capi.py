@@ -85,7 +85,7 @@ class rt_stats(C.Structure):
                 ("ms_device", C.c_double), ("ms_raygen", C.c_double), ("ms_intersect", C.c_double),
                 ("ms_shade", C.c_double), ("ms_mesh", C.c_double), ("ms_tail", C.c_double),
                 ("n_intersect_launches", C.c_uint32), ("n_mesh_launches", C.c_uint32),
-                ("mesh_rays", C.c_uint64), ("intersect_rays", C.c_uint64)]
+                ("mesh_rays", C.c_uint64), ("intersect_rays", C.c_uint64), ("mesh_records", C.c_uint64)]
 
 
 class rt_hit(C.Structure):
@@ -124,7 +124,7 @@ SIGNATURES = {
 
 def load(path=None):
     """Load librt_amd.so and attach the prototypes.  Raises if it is missing."""
-    path = path or LIB_PATH
+    path = path or os.environ.get("RT_AMD_LIB") or LIB_PATH  # RT_AMD_LIB: another build of the same library (experiments)
     if not os.path.exists(path):
         raise ImportError(
             "raytracer_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "

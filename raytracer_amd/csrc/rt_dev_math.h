@@ -13,13 +13,16 @@
 // out of line) run at 2: at 1 the CSG + torus variant took 257 registers and flipped between 3.4 and 5.2 ms per
 // 4K csg.scene frame with unrelated edits; held to 256 it is at 3.3 ms (torus.scene unchanged).
 #ifndef RT_PLAIN_WAVES
-#define RT_PLAIN_WAVES 4
+#define RT_PLAIN_WAVES 3
 #endif
 #ifndef RT_TORUS_WAVES
 #define RT_TORUS_WAVES 2
 #endif
 #ifndef RT_CSG_WAVES
 #define RT_CSG_WAVES 3
+#endif
+#ifndef RT_MEDIUM_WAVES
+#define RT_MEDIUM_WAVES 2
 #endif
 // The CSG evaluators are inlined into the kernel: device functions cannot carry amdgpu_waves_per_eu, so
 // out of line they took 166-250 registers whatever the kernel asked for, and every call passed its

@@ -37,14 +37,16 @@ struct HitBuf {
 #endif
 #define RT_MESH_OCC __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, RT_MESH_WAVES)))
 
-// k_intersect streams rays in and hit records out: without CSG it is worth 4 waves per SIMD (a few
-// spilled registers against twice the loads in flight: 1.06 -> 0.87 ms per 4K frame, measured)
+// k_intersect, waves per SIMD per variant (rt_dev_math.h): with the shading in the same kernel the plain
+// variant is best at 3 (4K mesh.scene intersect stage 1.03 ms against 1.08 at 4: 71 spilled registers there),
+// the fog variants at 2 (fog_light 8K x 16: 123 ms per frame against 138 at 3), CSG alone stays at 3
+// (room 1080p 28.6 ms against 30.3 at 2).
 #ifndef RT_TAIL_WAVES
 #define RT_TAIL_WAVES 3 // 4K mesh.scene tail 0.36 -> 0.34 ms against 2 (41 spilled registers); cornell_box 0.26 -> 0.27
 #endif
 // k_tail without CSG / fog / torus code (the bench scene's variant): waves per SIMD it is compiled for
 #define RT_TAIL_OCC __attribute__((amdgpu_waves_per_eu((CSG || MEDIUM || TORUS) ? 1 : RT_TAIL_WAVES)))
-#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(TORUS ? RT_TORUS_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES))))
+#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(TORUS ? RT_TORUS_WAVES : (MEDIUM ? RT_MEDIUM_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES)))))
 
 struct PassParams {
     uint64_t seed;
@@ -56,6 +58,9 @@ struct PassParams {
 };
 
 #define RT_BLOCK 256
+#ifndef RT_ISECT_BLOCK
+#define RT_ISECT_BLOCK 256 // threads per k_intersect workgroup (512: +3 %, 1024: +20 % on the 4K bench frame's intersect stage)
+#endif
 
 RT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -82,6 +87,34 @@ RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
     const uint32_t at = lds[n_waves] + lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
     __syncthreads();
     return at;
+}
+
+// Two appends with one exchange: list a and list b of the same block (a thread may be in at most one).
+// `lds` holds 2 * (blockDim.x / 64 + 1) words.
+RT_DEV void block_append2(bool a, bool b, uint32_t *counter_a, uint32_t *counter_b, uint32_t *lds, uint32_t &at_a, uint32_t &at_b)
+{
+    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (lane_id() == 0) {
+        lds[wave] = (uint32_t)__popcll(ma);
+        lds[n_waves + 1 + wave] = (uint32_t)__popcll(mb);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) { // thread 0 sums list a, thread 1 list b
+        uint32_t *l = lds + threadIdx.x * (n_waves + 1);
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; ++w) {
+            uint32_t c = l[w];
+            l[w] = total;
+            total += c;
+        }
+        l[n_waves] = total ? atomicAdd(threadIdx.x ? counter_b : counter_a, total) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane_id()) - 1ull;
+    at_a = lds[n_waves] + lds[wave] + (uint32_t)__popcll(ma & lt);
+    at_b = lds[2 * n_waves + 1] + lds[n_waves + 1 + wave] + (uint32_t)__popcll(mb & lt);
+    __syncthreads();
 }
 
 #ifndef RT_BLOCK_WIDE

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "rt_k_common.h"
+#include "rt_k_material.h"
 
 // ------------------------------------------------------------------ nearest hit
 struct Candidate {
@@ -152,13 +153,6 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
 // `mesh_queue`; k_mesh then walks the mesh grids and merges its result into the
 // hit record.  CSG / MEDIUM prune code (and registers) the
 // scene does not need.
-struct HitRec {
-    double t; // -1: nothing hit
-    d3 n;
-    double u, v;
-    int obj;
-};
-
 // Ray::trace (system.rs:122-133) over every object except the triangle work; returns whether
 // the ray still has to visit a mesh.
 template <bool CSG, bool MEDIUM, bool TORUS>
@@ -264,42 +258,124 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
     return wants_mesh;
 }
 
-template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS>
-__global__ void __launch_bounds__(RT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr, HitBuf hit,
+// One path segment per ray: nearest hit over the analytic objects (Ray::trace, system.rs:122-133), then
+//  - a ray that still has to visit a mesh is appended to the mesh record queue (`mq` + `mqh`, indexed by queue
+//    position): origin, direction, attenuation so far, pixel keys and the hit found so far.  k_mesh reads the
+//    records by position (no gather), merges the triangles' nearest hit into them, k_shade finishes them;
+//  - every other ray is finished here (FUSED): hit_color + Material::scatter (system.rs:135-142) straight from
+//    registers - its hit record never goes to memory - and the scattered ray is appended to `qout`, or the
+//    path's colour is added to its pixel.
+// !FUSED (rt_trace_rays): no shading; the hit record of every ray i goes to `hit[i]`, and mesh records carry i
+// in their slot field so that k_copy_mesh_hits can put the merged hit back.
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED>
+__global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
-                                                         uint32_t *mesh_queue, uint32_t *mesh_count)
+                                                         RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
+                                                         uint32_t *count_out, double *fb, HitBuf hit)
 {
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
-    __shared__ uint32_t append_lds[RT_BLOCK / 64 + 1];
+    __shared__ uint32_t append_lds[2 * (RT_ISECT_BLOCK / 64 + 1)];
     const uint32_t count = *count_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
+    const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
     Guards gd;
     for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
     gd.overflow = 0u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
         const uint32_t i = base + threadIdx.x;
-        bool wants_mesh = false;
-        d3 o, d;
-        uint32_t pixel = 0u;
-        if (i < count && !fetch_ray(sc, q, pp, i, o, d, pixel)) {
-            hit.obj[i] = RT_HIT_PADDING;
-        } else if (i < count) {
-            HitRec h;
+        bool wants_mesh = false, alive = false;
+        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(1.0, 1.0, 1.0);
+        uint32_t pixel = 0u, slot = i;
+        HitRec h;
+        h.t = -1.0;
+        h.n = mk3(0, 0, 0);
+        h.u = h.v = 0.0;
+        h.obj = -1;
+        if (i < count && fetch_ray(sc, q, pp, i, o, d, pixel)) {
+            if (FUSED) {
+                if (q.primary) {
+                    slot = q.row_major ? pixel : i;
+                } else {
+                    slot = q.slot[i];
+                    thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
+                }
+            }
             wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
-            hit.t[i] = h.t;
-            hit.n[0][i] = h.n.x;
-            hit.n[1][i] = h.n.y;
-            hit.n[2][i] = h.n.z;
-            hit.uv[0][i] = h.u;
-            hit.uv[1][i] = h.v;
-            hit.obj[i] = h.obj;
-            if (primary_ids) primary_ids[ray_slot(q, i)] = h.obj;
+            if (primary_ids) primary_ids[FUSED ? slot : ray_slot(q, i)] = h.obj;
+            if (!FUSED) {
+                hit.t[i] = h.t;
+                hit.n[0][i] = h.n.x;
+                hit.n[1][i] = h.n.y;
+                hit.n[2][i] = h.n.z;
+                hit.uv[0][i] = h.u;
+                hit.uv[1][i] = h.v;
+                hit.obj[i] = h.obj;
+            } else if (!wants_mesh) {
+                d3 X;
+                alive = shade_one(sc, o, d, thr, pixel, h, pp, bg, X);
+                if (!alive) {
+                    double *px = fb + (size_t)slot * 3;
+                    px[0] += thr.x * X.x;
+                    px[1] += thr.y * X.y;
+                    px[2] += thr.z * X.z;
+                }
+            }
         }
-        uint32_t at = block_append(wants_mesh, mesh_count, append_lds);
-        if (wants_mesh) mesh_queue[at] = i;
+        uint32_t at_m, at_q;
+        block_append2(wants_mesh, alive, mesh_count, count_out, append_lds, at_m, at_q);
+        if (wants_mesh) {
+            mq.o[0][at_m] = o.x;
+            mq.o[1][at_m] = o.y;
+            mq.o[2][at_m] = o.z;
+            mq.d[0][at_m] = d.x;
+            mq.d[1][at_m] = d.y;
+            mq.d[2][at_m] = d.z;
+            if (FUSED) {
+                mq.thr[0][at_m] = thr.x;
+                mq.thr[1][at_m] = thr.y;
+                mq.thr[2][at_m] = thr.z;
+            }
+            mq.slot[at_m] = slot;
+            mq.pixel[at_m] = pixel;
+            mqh.t[at_m] = h.t;
+            mqh.n[0][at_m] = h.n.x;
+            mqh.n[1][at_m] = h.n.y;
+            mqh.n[2][at_m] = h.n.z;
+            mqh.uv[0][at_m] = h.u;
+            mqh.uv[1][at_m] = h.v;
+            mqh.obj[at_m] = h.obj;
+        }
+        if (FUSED && alive) {
+            qout.o[0][at_q] = o.x;
+            qout.o[1][at_q] = o.y;
+            qout.o[2][at_q] = o.z;
+            qout.d[0][at_q] = d.x;
+            qout.d[1][at_q] = d.y;
+            qout.d[2][at_q] = d.z;
+            qout.thr[0][at_q] = thr.x;
+            qout.thr[1][at_q] = thr.y;
+            qout.thr[2][at_q] = thr.z;
+            qout.slot[at_q] = slot;
+            qout.pixel[at_q] = pixel;
+        }
     }
     for (int k = 0; k < 5; ++k)
         if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
     if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
+}
+
+// rt_trace_rays: the merged hit of mesh record j back to its ray's slot in the per-ray hit buffer
+__global__ void k_copy_mesh_hits(RayQueue mq, HitBuf mqh, const uint32_t *mesh_count, HitBuf hit)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *mesh_count) return;
+    const uint32_t i = mq.slot[j];
+    hit.t[i] = mqh.t[j];
+    hit.n[0][i] = mqh.n[0][j];
+    hit.n[1][i] = mqh.n[1][j];
+    hit.n[2][i] = mqh.n[2][j];
+    hit.uv[0][i] = mqh.uv[0][j];
+    hit.uv[1][i] = mqh.uv[1][j];
+    hit.obj[i] = mqh.obj[j];
 }

@@ -42,7 +42,8 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
     if (primary_ids) primary_ids[ray_slot(q, i)] = best_obj;
 }
 
-// Pass 2: the rays queued by k_intersect against the mesh objects
+// Pass 2: the mesh records queued by k_intersect (`q` + `hit`, both indexed by queue position: ray, pixel
+// keys and the nearest hit among the other objects) against the mesh objects
 // (Composite::intersect over Mesh children, composite.rs:20-34, mesh.rs:116-128).
 // A mesh hit replaces the recorded hit when it is nearer, or equally near and
 // earlier in the object list - the order Ray::trace's min_by would have seen.
@@ -116,7 +117,7 @@ __device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, 
 // JOBS_LDS: every job record is in LDS (at most DEV_MESH_JOBS_LDS of them).  A compile-time fact on purpose:
 // a run-time choice between the LDS copy and memory makes each field access a flat load.
 template <bool KD, bool JOBS_LDS>
-__global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
+__global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q,
                                                       const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
                                                       uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
                                                       PassParams pp)
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
             if (takes) {
                 const uint64_t j = cursor + (uint64_t)__popcll(empty & lane_lt);
                 if (j < block_end && j < count) {
-                    ri = mesh_queue[j];
+                    ri = (uint32_t)j; // the queue holds records, read by position
                     uint32_t px_;
                     (void)fetch_ray(sc, q, pp, ri, wo, wd, px_);
                     best_obj = hit.obj[ri];
@@ -645,15 +646,14 @@ RT_DEV bool mesh_brute_wave(const DevScene &sc, d3 o, d3 d, int &best_obj, doubl
     return replaced;
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q, const uint32_t *mesh_queue,
+__global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q,
                                                           const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
                                                           PassParams pp)
 {
     const uint32_t count = *mesh_count;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t j = wave; j < count; j += n_waves) {
-        const uint32_t i = mesh_queue[j];
+    for (uint32_t i = wave; i < count; i += n_waves) { // mesh records, by position
         d3 o, d;
         uint32_t px_;
         (void)fetch_ray(sc, q, pp, i, o, d, px_);

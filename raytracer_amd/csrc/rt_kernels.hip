@@ -63,9 +63,9 @@ static bool rt_debug() { static int v = -1; if (v < 0) v = getenv("RT_DEBUG") ? 
 // Either carved from one hipMalloc that the scene owns and grows on demand, or (rt_render_device_noalloc)
 // from the static device array `rt_noalloc_scratch`.
 struct Workspace {
-    RayQueue q[2];
-    HitBuf hit;
-    uint32_t *mesh_queue = nullptr; // ray indices that need the mesh walk this pass
+    RayQueue q[2]; // ping-pong ray queues
+    RayQueue mq;   // mesh record queue, ray part: the rays that have to visit a mesh this pass, by queue position
+    HitBuf mqh;    // mesh record queue, hit part: their nearest hit so far (k_mesh merges the triangles' into it)
     uint32_t *d_counts = nullptr;   // 2 x (depth_cap + 2) + 2: live rays per depth, mesh-queue lengths per depth, k_tail's lane totals
     uint32_t *d_guards = nullptr;   // 8
     size_t cap = 0;                 // ray slots
@@ -78,8 +78,8 @@ struct Workspace {
 // process ends; the name below is only a host-side handle for hipGetSymbolAddress - host code uses the
 // per-device pointer obtained at set-up (rt_scene_create), never the name.
 // RT_NOALLOC_MAX_SLOTS, RT_NOALLOC_MAX_DEPTH: rt_api.h
-#define RT_WS_BYTES_PER_SLOT 216u // carve_workspace: 24 f64 + 6 u32 arrays
-#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 4096u) // 87.8 MiB
+#define RT_WS_BYTES_PER_SLOT 292u // carve_workspace: 33 f64 + 7 u32 arrays (two ray queues of 80 B, mesh records of 132 B)
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 4096u) // 95.8 MiB
 static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
 #define RT_MAX_DEVICES 64
 static void *g_noalloc_ptr[RT_MAX_DEVICES]; // device address of rt_noalloc_scratch, per device
@@ -142,25 +142,25 @@ static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Worksp
     };
     Workspace tmp;
     Workspace &o = w ? *w : tmp;
-    for (int k = 0; k < 2; ++k) {
-        for (int c = 0; c < 3; ++c) o.q[k].o[c] = (double *)take(n, 8);
-        for (int c = 0; c < 3; ++c) o.q[k].d[c] = (double *)take(n, 8);
-        for (int c = 0; c < 3; ++c) o.q[k].thr[c] = (double *)take(n, 8);
+    RayQueue *queues[3] = {&o.q[0], &o.q[1], &o.mq};
+    for (RayQueue *rq : queues) {
+        for (int c = 0; c < 3; ++c) rq->o[c] = (double *)take(n, 8);
+        for (int c = 0; c < 3; ++c) rq->d[c] = (double *)take(n, 8);
+        for (int c = 0; c < 3; ++c) rq->thr[c] = (double *)take(n, 8);
     }
-    o.hit.t = (double *)take(n, 8);
-    for (int c = 0; c < 3; ++c) o.hit.n[c] = (double *)take(n, 8);
-    for (int c = 0; c < 2; ++c) o.hit.uv[c] = (double *)take(n, 8);
-    for (int k = 0; k < 2; ++k) {
-        o.q[k].slot = (uint32_t *)take(n, 4);
-        o.q[k].pixel = (uint32_t *)take(n, 4);
-        o.q[k].primary = 0;
-        o.q[k].row_major = 0;
-        o.q[k].rank = o.q[k].s_i = o.q[k].s_j = 0u;
-        o.q[k].recip_sqrt_spp = 1.0;
-        std::memset(&o.q[k].g, 0, sizeof(o.q[k].g));
+    o.mqh.t = (double *)take(n, 8);
+    for (int c = 0; c < 3; ++c) o.mqh.n[c] = (double *)take(n, 8);
+    for (int c = 0; c < 2; ++c) o.mqh.uv[c] = (double *)take(n, 8);
+    for (RayQueue *rq : queues) {
+        rq->slot = (uint32_t *)take(n, 4);
+        rq->pixel = (uint32_t *)take(n, 4);
+        rq->primary = 0;
+        rq->row_major = 0;
+        rq->rank = rq->s_i = rq->s_j = 0u;
+        rq->recip_sqrt_spp = 1.0;
+        std::memset(&rq->g, 0, sizeof(rq->g));
     }
-    o.hit.obj = (int32_t *)take(n, 4);
-    o.mesh_queue = (uint32_t *)take(n, 4);
+    o.mqh.obj = (int32_t *)take(n, 4);
     o.d_counts = (uint32_t *)take(2 * ((size_t)max_depth + 2) + 2, 4);
     o.d_guards = (uint32_t *)take(8, 4);
     o.cap = cap;
@@ -363,15 +363,30 @@ static int check_options(const rt_options *o)
 
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
-// nearest hit for the `count_ptr[0]` rays of `q`: the analytic pass, then the mesh pass
-// returns 1 when the grid walk (k_mesh) ran, 0 otherwise; `mid` (if any) is recorded between the two stages
-static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q, const uint32_t *count_ptr,
-                            uint32_t *mesh_count, const PassParams &pp, int32_t *ids, hipEvent_t mid)
+// One depth level for the `count_ptr[0]` rays of `q`: k_intersect (nearest analytic hit; rays with no mesh to
+// visit are shaded there and then), then for the mesh records it queued k_mesh | k_mesh_brute (the triangles)
+// and k_shade.  Survivors of both go to `qout` / `count_out`, finished paths to `fb`.
+// fused == false (rt_trace_rays): no shading; every ray's hit record ends up in `hit_all`.
+// Returns 1 when the grid walk (k_mesh) ran, 0 otherwise.  Stage events (if any): ev_mid1 after k_intersect,
+// ev_mid2 after the mesh kernel.
+static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q,
+                            const uint32_t *count_ptr, uint32_t *mesh_count, const PassParams &pp, int32_t *ids,
+                            bool fused, const RayQueue &qout, uint32_t *count_out, double *fb, const HitBuf &hit_all,
+                            hipEvent_t ev_mid1, hipEvent_t ev_mid2)
 {
-    dim3 grid(grid_for(live)), block(RT_BLOCK);
-#define LAUNCH_I(C, M, T, L)                                                                                             \
-    hipLaunchKernelGGL((k_intersect<C, M, T, L>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, w.hit, pp, ids, w.d_guards, \
-                       w.mesh_queue, mesh_count)
+    uint64_t gb = ((uint64_t)live + RT_ISECT_BLOCK - 1) / RT_ISECT_BLOCK;
+    if (gb < 1) gb = 1;
+    if (gb > 256 * 8) gb = 256 * 8; // 256 CUs x 8 blocks, grid-stride beyond that
+    dim3 grid((uint32_t)gb), block(RT_ISECT_BLOCK);
+#define LAUNCH_I(C, M, T, L)                                                                                           \
+    do {                                                                                                               \
+        if (fused)                                                                                                     \
+            hipLaunchKernelGGL((k_intersect<C, M, T, L, true>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q,   \
+                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_intersect<C, M, T, L, false>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q,  \
+                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all); \
+    } while (0)
     // scenes whose tables do not fit LDS (scene_lds_bytes == 0) run the one variant that reads them from memory,
     // which is the most general one
     const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
@@ -387,7 +402,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     default: LAUNCH_I(true, true, true, false); break;
     }
 #undef LAUNCH_I
-    if (mid) (void)hipEventRecord(mid, st);
+    if (ev_mid1) (void)hipEventRecord(ev_mid1, st);
     int walked = 0;
     if (s->has_mesh) {
         // short queues: one wave per ray over all triangles; long queues: one lane per ray through the mesh grid
@@ -395,8 +410,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
             if (blocks > 256 * 8) blocks = 256 * 8;
             if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), block, 0, st, s->dev, q, w.mesh_queue, mesh_count,
-                               w.hit, ids, pp);
+            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), dim3(RT_BLOCK), 0, st, s->dev, w.mq, mesh_count, w.mqh, ids, pp);
         } else {
             // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
             // waves stay and refill their idle lanes from further blocks
@@ -409,8 +423,8 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             if (mb > max_wgs) mb = max_wgs;
             const bool jobs_lds = s->dev.n_jobs <= DEV_MESH_JOBS_LDS;
 #define LAUNCH_M(KD, JL, LDS_BYTES)                                                                                    \
-    hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, q, w.mesh_queue,   \
-                       mesh_count, w.hit, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
+    hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, w.mq,        \
+                       mesh_count, w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
             if (s->mesh_kd) {
                 if (jobs_lds)
                     LAUNCH_M(true, true, s->mesh_kd_lds_bytes);
@@ -424,6 +438,20 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             }
 #undef LAUNCH_M
             walked = 1;
+        }
+    }
+    if (ev_mid2) (void)hipEventRecord(ev_mid2, st);
+    if (s->has_mesh) {
+        if (fused) {
+            // the mesh records: hit_color + scatter, survivors appended behind k_intersect's
+            if (scene_lds_bytes(s->dev) != 0u)
+                hipLaunchKernelGGL(k_shade<true>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st,
+                                   s->dev, w.mq, mesh_count, w.mqh, qout, count_out, fb, pp);
+            else
+                hipLaunchKernelGGL(k_shade<false>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, w.mq,
+                                   mesh_count, w.mqh, qout, count_out, fb, pp);
+        } else {
+            hipLaunchKernelGGL(k_copy_mesh_hits, dim3((live + 255) / 256), dim3(256), 0, st, w.mq, w.mqh, mesh_count, hit_all);
         }
     }
     return walked;
@@ -562,15 +590,10 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     STAGE_EV(hipEventRecord(s->evp[1 + 4 * depth], st));
                     const RayQueue &q_in = depth == 0 ? q_primary : w.q[cur];
                     walked[depth] = (uint8_t)launch_intersect(s, w, st, live, q_in, w.d_counts + depth,
-                                                              w.d_counts + (opts->max_depth + 2) + depth, pp, ids,
-                                                              stage_times ? s->evp[2 + 4 * depth] : nullptr);
-                    STAGE_EV(hipEventRecord(s->evp[3 + 4 * depth], st));
-                    if (scene_lds_bytes(s->dev) != 0u)
-                        hipLaunchKernelGGL(k_shade<true>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st,
-                                           s->dev, q_in, w.d_counts + depth, w.hit, w.q[1 - cur], w.d_counts + depth + 1, d_rgb, pp);
-                    else
-                        hipLaunchKernelGGL(k_shade<false>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, q_in,
-                                           w.d_counts + depth, w.hit, w.q[1 - cur], w.d_counts + depth + 1, d_rgb, pp);
+                                                              w.d_counts + (opts->max_depth + 2) + depth, pp, ids, true,
+                                                              w.q[1 - cur], w.d_counts + depth + 1, d_rgb, w.mqh,
+                                                              stage_times ? s->evp[2 + 4 * depth] : nullptr,
+                                                              stage_times ? s->evp[3 + 4 * depth] : nullptr);
                     STAGE_EV(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;
@@ -652,6 +675,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                             local.n_mesh_launches++;
                             local.mesh_rays += mesh_counts[k];
                         }
+                        local.mesh_records += mesh_counts[k];
                     }
                     if (tail_at >= 0) {
                         HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[1 + 4 * tail_at], s->evp[2 + 4 * tail_at]));
@@ -860,17 +884,27 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     pp.force_uv = 1;
     pp.bias = 0.0;
     HIP_TRY(hipMemset(w.d_counts + 3, 0, sizeof(uint32_t)));
-    (void)launch_intersect(s, w, nullptr, n32, w.q[0], w.d_counts, w.d_counts + 3, pp, nullptr, nullptr);
+    // the per-ray hit records live in the arrays of the second ray queue, which this call does not use otherwise
+    HitBuf hit;
+    hit.t = w.q[1].o[0];
+    hit.n[0] = w.q[1].o[1];
+    hit.n[1] = w.q[1].o[2];
+    hit.n[2] = w.q[1].d[0];
+    hit.uv[0] = w.q[1].d[1];
+    hit.uv[1] = w.q[1].d[2];
+    hit.obj = (int32_t *)w.q[1].slot;
+    (void)launch_intersect(s, w, nullptr, n32, w.q[0], w.d_counts, w.d_counts + 3, pp, nullptr, false, w.q[1], w.d_counts + 4,
+                           nullptr, hit, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     std::vector<int32_t> obj(n);
     std::vector<double> cols[6];
-    double *src[6] = {w.hit.t, w.hit.n[0], w.hit.n[1], w.hit.n[2], w.hit.uv[0], w.hit.uv[1]};
+    double *src[6] = {hit.t, hit.n[0], hit.n[1], hit.n[2], hit.uv[0], hit.uv[1]};
     for (int c = 0; c < 6; ++c) {
         cols[c].resize(n);
         HIP_TRY(hipMemcpy(cols[c].data(), src[c], n * sizeof(double), hipMemcpyDeviceToHost));
     }
-    HIP_TRY(hipMemcpy(obj.data(), w.hit.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(obj.data(), hit.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
         hits[i].t = cols[0][i];
         hits[i].n[0] = cols[1][i];

@@ -19,6 +19,14 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
+def use_library(path):
+    """Load another build of the oracle (bench.py's cpu_baseline: the -march=native build made on the box)."""
+    global _lib, ORACLE_LIB
+    ORACLE_LIB = path
+    _lib = None
+    return lib()
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -29,5 +29,8 @@ for k in sorted(fetch):
     out[k + "_launches"] = nf[k]
     out[k + "_fetch_bytes_per_launch"] = f
     out[k + "_write_bytes_per_launch"] = w
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+import bench
+out["sources_sha256"] = bench.kernel_sources_sha()
 json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
