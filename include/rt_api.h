@@ -233,17 +233,56 @@ void rt_scene_destroy(rt_scene *scene);
 /* Replaces system::render (system.rs:263-307) for a whole image on one GPU.
  * rgb_sum: H*W*3 doubles, row-major, SUM over strata (not divided).
  * primary_ids: H*W or NULL; object index of the primary hit in stratum 0,
- * -1 for a miss.  stats, cb may be NULL. */
+ * -1 for a miss.  stats, cb may be NULL; without cb nothing leaves the GPU
+ * before the frame is done.  The scene keeps the device-side frame between
+ * calls (grown on demand). */
 int rt_render(rt_scene *scene, const rt_options *opts, double *rgb_sum, int32_t *primary_ids, rt_stats *stats,
               rt_progress_cb cb, void *user);
 
 /* Same, for one shard of the tiles, on caller-provided DEVICE buffers and a
  * caller-provided stream (hipStream_t, NULL = default).  Outputs are in shard
  * layout: rt_shard_pixels(opts) entries, tile after tile (see
- * rt_unshard_device).  Asynchronous on `stream` except for reading back the
- * queue length every few bounces. */
+ * rt_unshard_device).  All work is queued on `stream`; the call returns when it has
+ * finished (the host follows the queue lengths from pass to pass and fills `stats`),
+ * so the outputs are complete on return. */
 int rt_render_device(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,
                      rt_stats *stats, void *stream);
+
+/* RenderProgress (system.rs:223-227) for renders whose frame stays on the device.  The reference's
+ * CliRenderProgress counts strata in sample_finished and rewrites out.png from the running sum at most
+ * every 5 s, dividing by strata_done + 1 (main.rs:174-185,219-222).  Handing 24 bytes per pixel to the host
+ * after every stratum is what that costs; here the cheap callback carries no image, and the snapshot
+ * callback is only called when due, with the running sum already tone-mapped on the device (3 bytes per
+ * pixel cross PCIe).  Either callback may be NULL; a non-zero return stops the render after that stratum. */
+typedef int (*rt_stratum_cb)(void *user, uint32_t strata_done, uint32_t strata_total);
+/* rgb8: n_pixels * 3 bytes of host memory owned by the library, valid during the call.  Layout: that of the
+ * render's outputs - shard slots for rt_render_device_progress (rt_shard_map gives the pixel of each slot;
+ * row-major with RT_FLAG_ROW_MAJOR), the row-major image for rt_render_multi. */
+typedef int (*rt_snapshot_cb)(void *user, uint32_t strata_done, uint32_t strata_total, const uint8_t *rgb8, uint64_t n_pixels);
+typedef struct rt_progress {
+    rt_stratum_cb on_stratum;   /* after every stratum (sample_finished's count)                       */
+    rt_snapshot_cb on_snapshot; /* after a stratum that is not the last, when min_interval_ms have passed
+                                 * since the render began or since the last snapshot                     */
+    uint32_t min_interval_ms;   /* 5000 in main.rs:178; 0 = after every stratum                         */
+    uint32_t reserved;
+    void *user;
+} rt_progress;
+
+/* rt_render_device with progress reporting (progress may be NULL). */
+int rt_render_device_progress(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,
+                              rt_stats *stats, void *stream, const rt_progress *progress);
+
+/* system::render for a whole image over n_devices GPUs of this process.  The reference's one parallel step
+ * spreads strata over threads and merges them under a mutex (system.rs:288-299); here the tiles of the image
+ * are spread over the GPUs (tile k to scenes[k % n_devices], opts->shard_* are ignored), each GPU runs its
+ * wavefront loop from its own host thread, and the finished tiles are gathered over xGMI to scenes[0]'s GPU,
+ * which scatters them into the row-major image (combine_renderbuf's counterpart) and hands it to the host.
+ * scenes[k]: the same description created with GPU k current (rt_scene_create); the same device may appear
+ * more than once.  rgb_sum: H*W*3 doubles, host; primary_ids: H*W or NULL; stats: rays and counters summed
+ * over the devices, ms_device of the slowest; progress (may be NULL): on_stratum when every GPU has finished
+ * that stratum, on_snapshot with the row-major image assembled from all shards. */
+int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts, double *rgb_sum,
+                    int32_t *primary_ids, rt_stats *stats, const rt_progress *progress);
 
 /* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same outputs (bit for

@@ -11,7 +11,8 @@ lib = _capi.load()
 
 from . import sdl, system  # noqa: E402
 from .sdl import Scene, parse, parse_file  # noqa: E402
-from .system import Options, RenderProgress, render, DeviceScene, tonemap, tonemap_device, write_png  # noqa: E402
+from .system import (Options, RenderProgress, render, DeviceScene, DeviceProgress, FileRenderProgress,  # noqa: E402
+                     render_multi, tonemap, tonemap_device, write_png)
 
 __all__ = ["lib", "sdl", "system", "Scene", "parse", "parse_file", "Options", "RenderProgress", "render",
-           "DeviceScene", "tonemap", "tonemap_device", "write_png"]
+           "DeviceScene", "DeviceProgress", "FileRenderProgress", "render_multi", "tonemap", "tonemap_device", "write_png"]

@@ -94,6 +94,14 @@ class rt_hit(C.Structure):
 
 
 rt_progress_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double))
+rt_stratum_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
+rt_snapshot_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64)
+
+
+class rt_progress(C.Structure):
+    _fields_ = [("on_stratum", rt_stratum_cb), ("on_snapshot", rt_snapshot_cb), ("min_interval_ms", C.c_uint32),
+                ("reserved", C.c_uint32), ("user", C.c_void_p)]
+
 
 # every symbol include/rt_api.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -103,6 +111,10 @@ SIGNATURES = {
                             C.POINTER(rt_stats), rt_progress_cb, C.c_void_p]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p, C.POINTER(rt_stats),
                                    C.c_void_p]),
+    "rt_render_device_progress": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p,
+                                            C.POINTER(rt_stats), C.c_void_p, C.POINTER(rt_progress)]),
+    "rt_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rt_options), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_int32), C.POINTER(rt_stats), C.POINTER(rt_progress)]),
     "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p,
                                            C.POINTER(rt_stats), C.c_void_p]),
     "rt_shard_pixels": (C.c_uint64, [C.POINTER(rt_options)]),

@@ -285,6 +285,9 @@ struct Decoder {
         u8(); // Ss
         u8(); // Se
         u8(); // Ah/Al
+        // A scan with one component is not interleaved: its MCU is one 8x8 block in raster order, whatever the
+        // sampling factors in the frame header say (T.81 A.2.2)
+        if (ncomp == 1) comp[0].h = comp[0].v = 1;
         const int hmax = comp[0].h, vmax = comp[0].v;
         const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
         const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;

@@ -186,7 +186,7 @@ struct DevScene {
     uint32_t n_dist_words;  // words in grid_dist
     uint32_t n_jobs;
     uint32_t n_leaves, n_meshes, n_materials, n_textures;
-    uint32_t pad2;
+    uint32_t starts_in_lds; // k_mesh keeps cell_start in LDS too (they fit beside the other grid tables)
     double background[3];
     double cam_fov_factor;
     double cam_c2w[16];

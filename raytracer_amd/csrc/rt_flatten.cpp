@@ -500,6 +500,16 @@ struct Flattener {
             throw Err{RT_ERR_UNSUPPORTED, "mesh with a transformation of its own"};
         if (nd.child_a < 0 || (uint32_t)nd.child_a >= d->n_meshes) throw Err{RT_ERR_INVALID, "mesh index out of range"};
         const rt_mesh &m = d->meshes[nd.child_a];
+        // the pools the caller's flatten pass filled: every range must lie inside them
+        if ((uint64_t)m.first_vertex + m.n_vertices > d->n_vertices || (m.n_vertices && !d->vertices))
+            throw Err{RT_ERR_INVALID, "mesh vertex range outside the vertex pool"};
+        if ((uint64_t)m.first_normal + m.n_normals > d->n_normals || (m.n_normals && !d->normals))
+            throw Err{RT_ERR_INVALID, "mesh normal range outside the normal pool"};
+        if ((uint64_t)m.first_triangle + m.n_triangles > d->n_triangles || (m.n_triangles && (!d->tri_v || !d->tri_n)))
+            throw Err{RT_ERR_INVALID, "mesh triangle range outside the triangle pool"};
+        // a mesh hit travels as (mesh index in its object) << 24 | triangle index
+        if (m.n_triangles > (1u << 24)) throw Err{RT_ERR_UNSUPPORTED, "mesh with more than 16 777 216 triangles"};
+        if ((int)out.meshes.size() - obj.mesh0 >= 255) throw Err{RT_ERR_UNSUPPORTED, "composite with more than 255 meshes"};
         DevMesh dm;
         std::memset(&dm, 0, sizeof(dm));
         dm.tri0 = (uint32_t)(out.tris.size() / 9);
@@ -773,8 +783,8 @@ struct Flattener {
             obj.frame = push_leaf(DL_NONE, W, O);
             obj.mesh0 = (int)out.meshes.size();
             for (int k = 0; k < root.child_b; ++k) {
-                int ci = root.child_a + k;
-                if (ci < 0 || (uint32_t)ci >= d->n_child_list) throw Err{RT_ERR_INVALID, "composite child out of range"};
+                int64_t ci = (int64_t)root.child_a + k;
+                if (ci < 0 || (uint64_t)ci >= d->n_child_list || !d->child_list) throw Err{RT_ERR_INVALID, "composite child out of range"};
                 emit_mesh(node(d->child_list[ci]), obj);
             }
             break;
@@ -875,6 +885,20 @@ int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
 {
     try {
         if (!desc) throw Err{RT_ERR_INVALID, "null scene description"};
+        {
+            const struct {
+                uint64_t n;
+                const void *p;
+                const char *what;
+            } arrays[] = {{desc->n_objects, desc->objects, "objects"},       {desc->n_nodes, desc->nodes, "nodes"},
+                          {desc->n_child_list, desc->child_list, "child_list"}, {desc->n_materials, desc->materials, "materials"},
+                          {desc->n_textures, desc->textures, "textures"},       {desc->n_images, desc->images, "images"},
+                          {desc->n_image_bytes, desc->image_data, "image_data"}, {desc->n_meshes, desc->meshes, "meshes"},
+                          {desc->n_vertices, desc->vertices, "vertices"},       {desc->n_normals, desc->normals, "normals"},
+                          {desc->n_triangles, desc->tri_v, "tri_v"},            {desc->n_triangles, desc->tri_n, "tri_n"}};
+            for (const auto &a : arrays)
+                if (a.n && !a.p) throw Err{RT_ERR_INVALID, std::string("null array with a non-zero count: ") + a.what};
+        }
         Flattener f{desc, out};
         for (uint32_t k = 0; k < desc->n_materials; ++k) {
             const rt_material &m = desc->materials[k];
@@ -952,6 +976,9 @@ int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
     } catch (const Err &e) {
         err = e.msg;
         return e.status;
+    } catch (const std::exception &e) { // bad_alloc, length_error: nothing unwinds across the C ABI
+        err = std::string("out of memory or size overflow while flattening the scene (") + e.what() + ")";
+        return RT_ERR_INVALID;
     }
     return RT_OK;
 }

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     uint2 *grid_lds = reinterpret_cast<uint2 *>(jobs_lds + n_jobs_lds);
     uint32_t *dist_lds = reinterpret_cast<uint32_t *>(grid_lds + (KD ? 0u : sc.n_grid_words));
     uint32_t *starts_lds = dist_lds + (KD ? 0u : sc.n_dist_words);
-    const bool starts_in_lds = !KD && sc.n_cell_starts <= DEV_GRID_MAX_STARTS;
+    const bool starts_in_lds = !KD && sc.starts_in_lds != 0u; // decided by rt_scene_create against the device's LDS limit
     uint2 *stk = grid_lds + threadIdx.x; // KD: this lane's stack column, entry e at stk[e * RT_MESH_LANES]
     {
         const uint32_t *jw = reinterpret_cast<const uint32_t *>(sc.jobs);

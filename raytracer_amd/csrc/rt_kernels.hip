@@ -26,8 +26,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_api.h"
@@ -115,6 +120,13 @@ struct rt_scene {
     std::vector<hipEvent_t> evp; // per-pass timing events: [0] before raygen, then 4 per depth
     std::vector<hipEvent_t> evr; // per depth: its queue length has been copied back
     std::vector<uint8_t> walked; // per depth: k_mesh (the grid walk) ran
+    // rt_render / rt_render_multi: output buffers kept on the device between calls, grown on demand
+    double *out_rgb = nullptr;
+    int32_t *out_ids = nullptr;
+    size_t out_cap = 0; // pixels
+    // progress snapshots: tone-mapped RGB8 on the device and in pinned host memory
+    uint8_t *snap_d = nullptr, *snap_h = nullptr;
+    size_t snap_cap = 0; // bytes
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -279,9 +291,24 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
         }
         RT_TRACE("mesh structure: %s (a triangle shares its grid cell with %.1f on average)", s->mesh_kd ? "kd-tree" : "grid", crowd);
     }
-    s->mesh_lds_bytes = (uint32_t)(std::min<size_t>(flat.jobs.size(), DEV_MESH_JOBS_LDS) * sizeof(DevMeshJob)) +
-                        s->dev.n_grid_words * 8u + s->dev.n_dist_words * 4u +
-                        (s->dev.n_cell_starts <= DEV_GRID_MAX_STARTS ? s->dev.n_cell_starts * 4u : 0u);
+    {
+        // dynamic LDS of k_mesh: job records, occupancy words, distance nibbles and - when they still fit the
+        // device's per-workgroup limit - the cell starts
+        int lds_limit = 0;
+        if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device) != hipSuccess || lds_limit <= 0)
+            lds_limit = 65536;
+        const uint32_t base = (uint32_t)(std::min<size_t>(flat.jobs.size(), DEV_MESH_JOBS_LDS) * sizeof(DevMeshJob)) +
+                              s->dev.n_grid_words * 8u + s->dev.n_dist_words * 4u;
+        const uint32_t starts = s->dev.n_cell_starts * 4u;
+        s->dev.starts_in_lds = (s->dev.n_cell_starts <= DEV_GRID_MAX_STARTS && base + starts <= (uint32_t)lds_limit) ? 1u : 0u;
+        s->mesh_lds_bytes = base + (s->dev.starts_in_lds ? starts : 0u);
+        if (s->mesh_lds_bytes > (uint32_t)lds_limit || s->mesh_kd_lds_bytes > (uint32_t)lds_limit) {
+            rt_host::set_last_error("rt_scene_create: the mesh grid tables (" + std::to_string(s->mesh_lds_bytes) +
+                                    " bytes) exceed the device's LDS per workgroup (" + std::to_string(lds_limit) + ")");
+            return fail(RT_ERR_UNSUPPORTED);
+        }
+        RT_TRACE("k_mesh LDS: %u bytes (cell starts %s), limit %d", s->mesh_lds_bytes, s->dev.starts_in_lds ? "in LDS" : "in memory", lds_limit);
+    }
     if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
     if ((rc = upload(s, flat.cell_tris, &s->dev.cell_tris))) return fail(rc);
     if ((rc = upload(s, flat.tri_n, &s->dev.tri_n))) return fail(rc);
@@ -316,6 +343,10 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     for (void *p : s->allocs) (void)hipFree(p);
     free_workspace(s);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    if (s->out_rgb) (void)hipFree(s->out_rgb);
+    if (s->out_ids) (void)hipFree(s->out_ids);
+    if (s->snap_d) (void)hipFree(s->snap_d);
+    if (s->snap_h) (void)hipHostFree(s->snap_h);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->evp) (void)hipEventDestroy(e);
@@ -356,6 +387,12 @@ static int check_options(const rt_options *o)
     }
     if ((uint64_t)o->width * o->height > 0xFFFFFFFFull || o->max_depth > 0xFFFFu) {
         rt_host::set_last_error("rt_options: image or depth too large for the random-number key");
+        return RT_ERR_INVALID;
+    }
+    // the key holds 16 bits of stratum (the reference's sample count is a u16, main.rs:66-69): with more,
+    // stratum 65536 + k would draw the numbers of stratum k
+    if (o->samples >= 65536u * 2u || (uint64_t)std::sqrt((double)o->samples) * (uint64_t)std::sqrt((double)o->samples) > 65536ull) {
+        rt_host::set_last_error("rt_options: more than 65536 strata do not fit the random-number key");
         return RT_ERR_INVALID;
     }
     return RT_OK;
@@ -490,7 +527,8 @@ typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
 // `fixed`: a workspace the caller provides (rt_render_device_noalloc); nothing is allocated then, and sizes
 // beyond what it and the scene's host side were set up for are refused.
 static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int32_t *d_ids, rt_stats *stats,
-                         hipStream_t st, stratum_fn per_stratum, void *user, const Workspace *fixed = nullptr)
+                         hipStream_t st, stratum_fn per_stratum, void *user, const Workspace *fixed = nullptr,
+                         bool call_back_for_empty_shards = false)
 {
     int rc = check_options(opts);
     if (rc) return rc;
@@ -692,12 +730,21 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
             }
         }
     }
+    if (!n_slots && call_back_for_empty_shards && per_stratum) {
+        // a shard without tiles still meets the other devices between strata (rt_render_multi)
+        for (uint32_t k = 1; k <= strata; ++k) {
+            int stop = per_stratum(user, k, strata);
+            if (stop < 0) return stop;
+            if (stop > 0) break;
+        }
+    }
 finished:
     HIP_TRY(hipMemcpyAsync(s->h_pinned, w.d_guards, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
     local.interval_overflow = s->h_pinned[5];
+    local.strata = n_slots ? done : strata; // fewer than floor(sqrt(samples))^2 when the callback stopped the render
 #ifdef RT_MESH_PROF
     {
         unsigned long long pf[12];
@@ -776,6 +823,92 @@ extern "C" int rt_tonemap_device(const double *d_rgb_sum, uint64_t n_pixels, dou
     return RT_OK;
 }
 
+// ---- output buffers that rt_render / rt_render_multi keep on the device between calls ------------------
+static int ensure_outputs(rt_scene *s, size_t n_px, bool want_ids)
+{
+    if (n_px > s->out_cap) {
+        if (s->out_rgb) (void)hipFree(s->out_rgb);
+        if (s->out_ids) (void)hipFree(s->out_ids);
+        s->out_rgb = nullptr;
+        s->out_ids = nullptr;
+        s->out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->out_rgb, n_px * 3 * sizeof(double)));
+        s->out_cap = n_px;
+    }
+    if (want_ids && !s->out_ids) HIP_TRY(hipMalloc((void **)&s->out_ids, s->out_cap * sizeof(int32_t)));
+    return RT_OK;
+}
+
+static int ensure_snapshot(rt_scene *s, size_t n_px)
+{
+    if (n_px * 3 > s->snap_cap) {
+        if (s->snap_d) (void)hipFree(s->snap_d);
+        if (s->snap_h) (void)hipHostFree(s->snap_h);
+        s->snap_d = nullptr;
+        s->snap_h = nullptr;
+        s->snap_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->snap_d, n_px * 3));
+        HIP_TRY(hipHostMalloc((void **)&s->snap_h, n_px * 3, hipHostMallocDefault));
+        s->snap_cap = n_px * 3;
+    }
+    return RT_OK;
+}
+
+// RenderProgress over device buffers (rt_progress, rt_api.h): on_stratum after every stratum; on_snapshot at
+// most every min_interval_ms and not after the last stratum, with the running sum tone-mapped on the device by
+// strata_done + 1 (CliRenderProgress::sample_finished, main.rs:174-185) and 3 bytes per pixel copied to the host
+struct ProgressCtx {
+    const rt_progress *p;
+    rt_scene *s;
+    const double *d_rgb;
+    size_t n_px;
+    hipStream_t st;
+    std::chrono::steady_clock::time_point last;
+};
+
+static int snapshot_to_host(rt_scene *s, const double *d_rgb, size_t n_px, uint32_t done, hipStream_t st)
+{
+    int rc = ensure_snapshot(s, n_px);
+    if (rc) return rc;
+    rc = rt_tonemap_device(d_rgb, n_px, (double)done + 1.0, s->snap_d, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(s->snap_h, s->snap_d, n_px * 3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+static int progress_stratum(void *u, uint32_t done, uint32_t total)
+{
+    ProgressCtx *c = (ProgressCtx *)u;
+    if (c->p->on_stratum && c->p->on_stratum(c->p->user, done, total)) return 1;
+    if (c->p->on_snapshot && done < total) {
+        const auto now = std::chrono::steady_clock::now();
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(now - c->last).count() >= (long long)c->p->min_interval_ms) {
+            c->last = now;
+            int rc = snapshot_to_host(c->s, c->d_rgb, c->n_px, done, c->st);
+            if (rc) return rc;
+            if (c->p->on_snapshot(c->p->user, done, total, c->s->snap_h, (uint64_t)c->n_px)) return 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" int rt_render_device_progress(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,
+                                         rt_stats *stats, void *stream, const rt_progress *progress)
+{
+    if (!progress || (!progress->on_stratum && !progress->on_snapshot))
+        return render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, nullptr, nullptr);
+    int rc = check_options(opts);
+    if (rc) return rc;
+    if (!scene) {
+        rt_host::set_last_error("rt_render_device_progress: null scene");
+        return RT_ERR_INVALID;
+    }
+    const size_t n_px = (opts->flags & RT_FLAG_ROW_MAJOR) ? (size_t)opts->width * opts->height : (size_t)rt_shard_pixels(opts);
+    ProgressCtx ctx{progress, scene, d_rgb_sum, n_px, (hipStream_t)stream, std::chrono::steady_clock::now()};
+    return render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, progress_stratum, &ctx);
+}
+
 struct HostRenderCtx {
     const rt_options *opts;
     double *d_full_rgb; // row-major running sum on the device
@@ -787,7 +920,6 @@ struct HostRenderCtx {
 static int host_render_stratum(void *u, uint32_t done, uint32_t total)
 {
     HostRenderCtx *c = (HostRenderCtx *)u;
-    if (!c->cb) return 0;
     size_t n = (size_t)c->opts->width * c->opts->height;
     if (hipMemcpy(c->h_rgb, c->d_full_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
         rt_host::set_last_error("rt_render: copy to host failed");
@@ -811,32 +943,264 @@ extern "C" int rt_render(rt_scene *scene, const rt_options *opts_in, double *rgb
     HIP_TRY(hipSetDevice(scene->device));
     opts.flags |= RT_FLAG_ROW_MAJOR; // the kernels write y * width + x directly
     const size_t n = (size_t)opts.width * opts.height;
-    double *d_full = nullptr;
-    int32_t *d_ids_full = nullptr;
-    auto cleanup = [&]() {
-        if (d_full) (void)hipFree(d_full);
-        if (d_ids_full) (void)hipFree(d_ids_full);
-    };
-#define TRY_OR_CLEAN(expr)                                                                                             \
-    do {                                                                                                               \
-        hipError_t e_ = (expr);                                                                                        \
-        if (e_ != hipSuccess) {                                                                                        \
-            rt_host::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                               \
-            cleanup();                                                                                                 \
-            return RT_ERR_DEVICE;                                                                                      \
-        }                                                                                                              \
-    } while (0)
-    TRY_OR_CLEAN(hipMalloc((void **)&d_full, n * 3 * sizeof(double)));
-    if (primary_ids) TRY_OR_CLEAN(hipMalloc((void **)&d_ids_full, n * sizeof(int32_t)));
-    HostRenderCtx ctx{&opts, d_full, rgb_sum, cb, user};
-    rc = render_strata(scene, &opts, d_full, d_ids_full, stats, nullptr, host_render_stratum, &ctx);
+    rc = ensure_outputs(scene, n, primary_ids != nullptr); // kept across calls, grown on demand
+    if (rc) return rc;
+    HostRenderCtx ctx{&opts, scene->out_rgb, rgb_sum, cb, user};
+    // without a callback nothing leaves the device before the frame is done (the reference hands the running
+    // sum to sample_finished after every stratum: 24 bytes per pixel each time)
+    rc = render_strata(scene, &opts, scene->out_rgb, primary_ids ? scene->out_ids : nullptr, stats, nullptr,
+                       cb ? host_render_stratum : nullptr, &ctx);
     if (rc == RT_OK) {
-        TRY_OR_CLEAN(hipMemcpy(rgb_sum, d_full, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-        if (primary_ids) TRY_OR_CLEAN(hipMemcpy(primary_ids, d_ids_full, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rgb_sum, scene->out_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (primary_ids) HIP_TRY(hipMemcpy(primary_ids, scene->out_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
-    cleanup();
     return rc;
-#undef TRY_OR_CLEAN
+}
+
+// ---- one frame over several GPUs of this process ---------------------------------------------------------
+// The reference's one parallel step spreads strata over threads and merges under a mutex (system.rs:288-299);
+// here tile shards are spread over GPUs (pixels are independent, system.rs:244-253) and the finished tiles are
+// gathered to the first scene's GPU over xGMI (hipMemcpyPeerAsync: every peer pushes over its own link), where
+// k_unshard scatters them into the row-major image.  One host thread per GPU drives that GPU's wavefront loop.
+namespace {
+struct MultiBarrier { // all device threads meet between strata when progress is reported
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t n = 0, waiting = 0, generation = 0;
+    bool aborted = false; // a device failed: nobody waits any more
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        if (aborted) return;
+        const uint32_t gen = generation;
+        if (++waiting == n) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return gen != generation || aborted; });
+        }
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+
+struct MultiShared {
+    const rt_progress *progress = nullptr;
+    rt_scene *const *scenes = nullptr;
+    uint32_t n = 0;
+    rt_options opts;
+    MultiBarrier barrier;
+    std::atomic<int> stop{0};
+    std::atomic<int> error{0};
+    std::chrono::steady_clock::time_point last;
+    std::vector<uint8_t> image;           // row-major RGB8 snapshot
+    std::vector<std::vector<uint32_t>> maps; // per shard: slot -> pixel
+    std::vector<std::string> messages;
+};
+
+struct MultiThreadCtx {
+    MultiShared *sh;
+    uint32_t k;
+    double *d_shard;
+    size_t n_slots;
+    hipStream_t st;
+};
+
+// per stratum, on every device thread; thread 0 talks to the caller
+int multi_stratum(void *u, uint32_t done, uint32_t total)
+{
+    MultiThreadCtx *c = (MultiThreadCtx *)u;
+    MultiShared *sh = c->sh;
+    const rt_progress *p = sh->progress;
+    if (!p) return sh->error.load() ? 1 : 0;
+    bool snap = false;
+    if (c->k == 0) {
+        if (p->on_stratum && p->on_stratum(p->user, done, total)) sh->stop.store(1);
+        if (p->on_snapshot && done < total) {
+            const auto now = std::chrono::steady_clock::now();
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(now - sh->last).count() >= (long long)p->min_interval_ms) {
+                sh->last = now;
+                snap = true;
+            }
+        }
+        sh->stop.fetch_or(snap ? 2 : 0);
+    }
+    sh->barrier.wait(); // every device has finished stratum `done`; thread 0's decisions are visible
+    const int flags = sh->stop.load();
+    if (flags & 2) {
+        rt_scene *s = sh->scenes[c->k];
+        if (c->n_slots && snapshot_to_host(s, c->d_shard, c->n_slots, done, c->st) != RT_OK) sh->error.store(1);
+        if (!sh->error.load()) {
+            const std::vector<uint32_t> &map = sh->maps[c->k];
+            for (size_t i = 0; i < c->n_slots; ++i)
+                if (map[i] != 0xFFFFFFFFu) std::memcpy(&sh->image[(size_t)map[i] * 3], s->snap_h + i * 3, 3);
+        }
+        sh->barrier.wait(); // the image is complete
+        if (c->k == 0) {
+            if (!sh->error.load() && p->on_snapshot(p->user, done, total, sh->image.data(), (uint64_t)sh->opts.width * sh->opts.height))
+                sh->stop.fetch_or(1);
+            sh->stop.fetch_and(~2);
+        }
+        sh->barrier.wait();
+    }
+    return (sh->stop.load() & 1) || sh->error.load() ? 1 : 0;
+}
+} // namespace
+
+extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts_in, double *rgb_sum,
+                               int32_t *primary_ids, rt_stats *stats, const rt_progress *progress)
+{
+    int rc = check_options(opts_in);
+    if (rc) return rc;
+    if (!scenes || n_devices == 0 || !rgb_sum) {
+        rt_host::set_last_error("rt_render_multi: null scenes or output, or no device");
+        return RT_ERR_INVALID;
+    }
+    for (uint32_t k = 0; k < n_devices; ++k)
+        if (!scenes[k]) {
+            rt_host::set_last_error("rt_render_multi: null scene");
+            return RT_ERR_INVALID;
+        }
+    const bool with_progress = progress && (progress->on_stratum || progress->on_snapshot);
+    MultiShared sh;
+    sh.progress = with_progress ? progress : nullptr;
+    sh.scenes = scenes;
+    sh.n = n_devices;
+    sh.opts = *opts_in;
+    sh.opts.shard_count = n_devices;
+    sh.opts.flags &= ~RT_FLAG_ROW_MAJOR;
+    sh.barrier.n = n_devices;
+    sh.last = std::chrono::steady_clock::now();
+    sh.messages.resize(n_devices);
+    const size_t n_px = (size_t)opts_in->width * opts_in->height;
+    std::vector<size_t> n_slots(n_devices);
+    for (uint32_t k = 0; k < n_devices; ++k) {
+        rt_options o = sh.opts;
+        o.shard_rank = k;
+        n_slots[k] = (size_t)rt_shard_pixels(&o);
+    }
+    if (with_progress && progress->on_snapshot) {
+        sh.image.assign(n_px * 3, 0);
+        sh.maps.resize(n_devices);
+        for (uint32_t k = 0; k < n_devices; ++k) {
+            rt_options o = sh.opts;
+            o.shard_rank = k;
+            sh.maps[k].resize(n_slots[k]);
+            if (n_slots[k] && (rc = rt_shard_map(&o, sh.maps[k].data()))) return rc;
+        }
+    }
+    // shard buffers on every device (kept by the scenes), the full image on the first
+    rt_scene *root = scenes[0];
+    for (uint32_t k = 0; k < n_devices; ++k) {
+        HIP_TRY(hipSetDevice(scenes[k]->device));
+        const size_t need = (k == 0 ? n_px : 0) + n_slots[k] + (k == 0 && n_devices > 1 ? *std::max_element(n_slots.begin(), n_slots.end()) : 0);
+        if ((rc = ensure_outputs(scenes[k], need ? need : 1, primary_ids != nullptr))) return rc;
+        if (scenes[k]->device != root->device) {
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, root->device, scenes[k]->device));
+            if (can) {
+                HIP_TRY(hipSetDevice(root->device));
+                hipError_t e = hipDeviceEnablePeerAccess(scenes[k]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    // layout of scenes[0]'s buffer: [full image | own shard | staging for a peer's shard]; of the others: [own shard]
+    auto shard_rgb = [&](uint32_t k) { return scenes[k]->out_rgb + (k == 0 ? n_px * 3 : 0); };
+    auto shard_ids = [&](uint32_t k) { return primary_ids ? scenes[k]->out_ids + (k == 0 ? n_px : 0) : (int32_t *)nullptr; };
+    std::vector<rt_stats> st(n_devices);
+    std::vector<int> rcs(n_devices, RT_OK);
+    std::vector<hipStream_t> streams(n_devices, nullptr);
+    std::vector<MultiThreadCtx> ctxs(n_devices);
+    auto worker = [&](uint32_t k) {
+        rt_options o = sh.opts;
+        o.shard_rank = k;
+        if (hipSetDevice(scenes[k]->device) != hipSuccess || hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) {
+            rcs[k] = RT_ERR_DEVICE;
+            sh.messages[k] = "cannot create a stream";
+            sh.error.store(1);
+            sh.barrier.abort();
+            streams[k] = nullptr;
+        }
+        ctxs[k] = MultiThreadCtx{&sh, k, shard_rgb(k), n_slots[k], streams[k]};
+        if (rcs[k] == RT_OK) {
+            // with progress every thread must pass the same barriers: an empty shard still walks the strata
+            rcs[k] = render_strata(scenes[k], &o, shard_rgb(k), shard_ids(k), &st[k], streams[k], with_progress ? multi_stratum : nullptr,
+                                   &ctxs[k], nullptr, /*call_back_for_empty_shards=*/true);
+            if (rcs[k] != RT_OK) {
+                sh.messages[k] = rt_last_error();
+                sh.error.store(1);
+                sh.barrier.abort();
+            }
+        }
+    };
+    if (n_devices == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t k = 0; k < n_devices; ++k) pool.emplace_back(worker, k);
+        for (auto &t : pool) t.join();
+    }
+    rc = RT_OK;
+    for (uint32_t k = 0; k < n_devices; ++k)
+        if (rcs[k] != RT_OK) {
+            rc = rcs[k];
+            rt_host::set_last_error("rt_render_multi: device " + std::to_string(k) + ": " + sh.messages[k]);
+        }
+    if (rc == RT_OK) {
+        // the one exchange step: every shard to the first GPU, scattered into the row-major image there
+        HIP_TRY(hipSetDevice(root->device));
+        hipStream_t s0 = streams[0];
+        double *stage_rgb = root->out_rgb + (n_px + n_slots[0]) * 3;
+        int32_t *stage_ids = primary_ids ? root->out_ids + n_px + n_slots[0] : nullptr;
+        for (uint32_t k = 0; k < n_devices && rc == RT_OK; ++k) {
+            rt_options o = sh.opts;
+            o.shard_rank = k;
+            if (n_slots[k] == 0) continue;
+            const double *src_rgb = shard_rgb(k);
+            const int32_t *src_ids = shard_ids(k);
+            if (k != 0) {
+                HIP_TRY(hipMemcpyPeerAsync(stage_rgb, root->device, src_rgb, scenes[k]->device, n_slots[k] * 3 * sizeof(double), s0));
+                if (primary_ids)
+                    HIP_TRY(hipMemcpyPeerAsync(stage_ids, root->device, src_ids, scenes[k]->device, n_slots[k] * sizeof(int32_t), s0));
+                src_rgb = stage_rgb;
+                src_ids = stage_ids;
+            }
+            rc = rt_unshard_device(&o, k, src_rgb, root->out_rgb, src_ids, primary_ids ? root->out_ids : nullptr, s0);
+        }
+        if (rc == RT_OK) {
+            HIP_TRY(hipMemcpyAsync(rgb_sum, root->out_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost, s0));
+            if (primary_ids) HIP_TRY(hipMemcpyAsync(primary_ids, root->out_ids, n_px * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+            HIP_TRY(hipStreamSynchronize(s0));
+        }
+    }
+    for (uint32_t k = 0; k < n_devices; ++k)
+        if (streams[k]) {
+            (void)hipSetDevice(scenes[k]->device);
+            (void)hipStreamDestroy(streams[k]);
+        }
+    if (stats && rc == RT_OK) {
+        *stats = st[0];
+        for (uint32_t k = 1; k < n_devices; ++k) {
+            stats->rays += st[k].rays;
+            stats->primary_rays += st[k].primary_rays;
+            stats->mesh_rays += st[k].mesh_rays;
+            stats->intersect_rays += st[k].intersect_rays;
+            stats->mesh_records += st[k].mesh_records;
+            stats->interval_overflow += st[k].interval_overflow;
+            for (int g = 0; g < 5; ++g) stats->guards[g] += st[k].guards[g];
+            if (st[k].bounce_passes > stats->bounce_passes) stats->bounce_passes = st[k].bounce_passes;
+            if (st[k].strata > stats->strata) stats->strata = st[k].strata;
+            if (st[k].ms_device > stats->ms_device) stats->ms_device = st[k].ms_device; // the slowest device
+        }
+    }
+    return rc;
 }
 
 extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const double *origins, const double *directions,

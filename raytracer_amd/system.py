@@ -85,12 +85,12 @@ class DeviceScene:
         stats = _capi.rt_stats()
 
         def _cb(user, done, total, ptr):
-            if progress is not None:
-                buf = np.ctypeslib.as_array(ptr, shape=(H, W, 3))
-                progress.sample_finished(options, buf)
+            buf = np.ctypeslib.as_array(ptr, shape=(H, W, 3))
+            progress.sample_finished(options, buf)
             return 0
 
-        cb = _capi.rt_progress_cb(_cb)
+        # no progress object, no callback: the frame then stays on the GPU until it is done
+        cb = _capi.rt_progress_cb(_cb) if progress is not None else _capi.rt_progress_cb()
         if progress is not None:
             progress.render_started(options)
         rc = self._lib.rt_render(self._h, C.byref(o), rgb.ctypes.data_as(C.POINTER(C.c_double)),
@@ -101,15 +101,22 @@ class DeviceScene:
         return rgb, ids, stats
 
     def render_shard(self, options, shard_rank, shard_count, d_rgb_ptr, d_ids_ptr=None, stream=None, row_major=False,
-                     stage_times=False):
+                     stage_times=False, progress=None):
         """One shard of the tiles into caller-owned device buffers (rt_render_device).  `row_major`
         (a single shard only): the buffers are width * height elements indexed y * width + x.
-        `stage_times`: fill the per-kernel times of the returned rt_stats."""
+        `stage_times`: fill the per-kernel times of the returned rt_stats.  `progress`: a DeviceProgress
+        (rt_render_device_progress)."""
         o = options.to_c(shard_rank, shard_count, (ROW_MAJOR if row_major else 0) | (STAGE_TIMES if stage_times else 0))
         stats = _capi.rt_stats()
-        rc = self._lib.rt_render_device(self._h, C.byref(o), C.c_void_p(d_rgb_ptr),
-                                        C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(stats),
-                                        C.c_void_p(stream) if stream else None)
+        if progress is None:
+            rc = self._lib.rt_render_device(self._h, C.byref(o), C.c_void_p(d_rgb_ptr),
+                                            C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(stats),
+                                            C.c_void_p(stream) if stream else None)
+        else:
+            p = progress.to_c()
+            rc = self._lib.rt_render_device_progress(self._h, C.byref(o), C.c_void_p(d_rgb_ptr),
+                                                     C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(stats),
+                                                     C.c_void_p(stream) if stream else None, C.byref(p))
         _check(self._lib, rc, "rt_render_device")
         return stats
 
@@ -125,6 +132,80 @@ class DeviceScene:
         _check(self._lib, rc, "rt_trace_rays")
         dt = np.dtype([("t", "f8"), ("n", "f8", 3), ("uv", "f8", 2), ("object", "i4"), ("pad", "i4")])
         return np.frombuffer(hits, dtype=dt, count=n).copy(), stats
+
+
+class DeviceProgress:
+    """rt_progress: RenderProgress for frames that stay on the device.  `on_stratum(done, total)` after every
+    stratum; `on_snapshot(done, total, rgb8)` at most every `min_interval` seconds (5 in main.rs:178) and not
+    after the last stratum, with the running sum tone-mapped by done + 1 as write_render_result_to_file does
+    (main.rs:174-185,219-222): rgb8 is a uint8 array [n_pixels, 3] in the layout of the render's outputs.
+    A callback that returns a true value stops the render."""
+
+    def __init__(self, on_stratum=None, on_snapshot=None, min_interval=5.0):
+        self.on_stratum, self.on_snapshot, self.min_interval = on_stratum, on_snapshot, min_interval
+        self._keep = None
+
+    def to_c(self):
+        p = _capi.rt_progress()
+        keep = []
+        if self.on_stratum is not None:
+            f = _capi.rt_stratum_cb(lambda user, done, total: 1 if self.on_stratum(done, total) else 0)
+            p.on_stratum = f
+            keep.append(f)
+        if self.on_snapshot is not None:
+            def _snap(user, done, total, ptr, n):
+                img = np.ctypeslib.as_array(ptr, shape=(int(n), 3))
+                return 1 if self.on_snapshot(done, total, img) else 0
+            f = _capi.rt_snapshot_cb(_snap)
+            p.on_snapshot = f
+            keep.append(f)
+        p.min_interval_ms = int(round(self.min_interval * 1000))
+        self._keep = keep  # the ctypes thunks must outlive the call
+        return p
+
+
+class FileRenderProgress(DeviceProgress):
+    """CliRenderProgress (main.rs:133-199) without the progress bar: counts strata, rewrites `filename` (PNG)
+    from a snapshot at most every 5 s while the render runs; `finish(rgb_sum, strata)` writes the final image
+    the way render_finished does (divisor strata + 1, the reference's own count)."""
+
+    def __init__(self, filename, width, height, min_interval=5.0):
+        super().__init__(self._count, self._snapshot, min_interval)
+        self.filename, self.width, self.height = str(filename), width, height
+        self.num_samples = 0
+        self.files_written = 0
+
+    def _count(self, done, total):
+        self.num_samples = done
+        return 0
+
+    def _snapshot(self, done, total, rgb8):
+        write_png(self.filename, rgb8.reshape(self.height, self.width, 3))
+        self.files_written += 1
+        return 0
+
+    def finish(self, rgb_sum, strata):
+        write_png(self.filename, tonemap(rgb_sum, strata + 1))
+        self.files_written += 1
+
+
+def render_multi(options, device_scenes, progress=None, want_ids=True):
+    """system::render over several GPUs of this process (rt_render_multi): device_scenes[k] is the scene
+    created with GPU k current -> (rgb_sum [H,W,3], ids [H,W] | None, rt_stats).  `progress`: DeviceProgress;
+    its snapshots are row-major images."""
+    from . import lib
+    o = options.to_c()
+    H, W = options.height, options.width
+    rgb = np.zeros((H, W, 3), dtype=np.float64)
+    ids = np.zeros((H, W), dtype=np.int32) if want_ids else None
+    stats = _capi.rt_stats()
+    handles = (C.c_void_p * len(device_scenes))(*[d._h for d in device_scenes])
+    p = progress.to_c() if progress is not None else None
+    rc = lib.rt_render_multi(handles, len(device_scenes), C.byref(o), rgb.ctypes.data_as(C.POINTER(C.c_double)),
+                             ids.ctypes.data_as(C.POINTER(C.c_int32)) if want_ids else None, C.byref(stats),
+                             C.byref(p) if p is not None else None)
+    _check(lib, rc, "rt_render_multi")
+    return rgb, ids, stats
 
 
 def shard_pixels(options, shard_rank, shard_count):

@@ -719,3 +719,101 @@ def test_analytic_cases_on_device(rt, case):
         getattr(test_analytic, case)(rt)
     finally:
         test_analytic.ON_DEVICE[0] = False
+
+
+def test_render_multi_equals_whole_and_reports_progress(rt, tmp_path):
+    """rt_render_multi (tiles over the GPUs of one process, gathered to the first): with every "device" this
+    one GPU the gathered frame equals the single-GPU frame bit for bit, for 1, 2, 3 and 8 shards; progress:
+    on_stratum once per stratum in order, snapshots only between strata, tone-mapped by done + 1 (main.rs:174-185),
+    assembled row-major from all shards; stopping from the callback ends the render after that stratum."""
+    o = rt.Options(width=300, height=200, samples=9, seed=4, tile_size=32)
+    sc = rt.parse_file(o, parity.scene_path("meshes2"), parity.ASSETS)
+    devs = [rt.DeviceScene(sc) for _ in range(8)]
+    whole, wids, wst = devs[0].render(o)
+    for n in (1, 2, 3, 8):
+        rgb, ids, st = rt.render_multi(o, devs[:n])
+        assert np.array_equal(rgb, whole) and np.array_equal(ids, wids), n
+        assert st.rays == wst.rays and st.strata == 9 and st.primary_rays == wst.primary_rays
+    # more shards than tiles: some devices own nothing
+    small = rt.Options(width=40, height=30, samples=4, seed=4, tile_size=32)
+    ssc = rt.parse_file(small, parity.scene_path("meshes2"), parity.ASSETS)
+    sdevs = [rt.DeviceScene(ssc) for _ in range(5)]
+    w2, i2, _ = sdevs[0].render(small)
+    strata_seen = []
+    r2, j2, s2 = rt.render_multi(small, sdevs, rt.DeviceProgress(on_stratum=lambda d, t: strata_seen.append((d, t)) and None,
+                                                                 on_snapshot=lambda d, t, img: None, min_interval=0.0))
+    assert np.array_equal(r2, w2) and np.array_equal(j2, i2) and strata_seen == [(1, 4), (2, 4), (3, 4), (4, 4)]
+    # progress: every stratum reported; with min_interval 0 a snapshot after every stratum but the last
+    calls, snaps = [], []
+    prog = rt.DeviceProgress(on_stratum=lambda d, t: calls.append((d, t)) and None,
+                             on_snapshot=lambda d, t, img: snaps.append((d, img.copy())) and None, min_interval=0.0)
+    rgb, ids, st = rt.render_multi(o, devs[:3], prog)
+    assert calls == [(k, 9) for k in range(1, 10)] and [d for d, _ in snaps] == list(range(1, 9))
+    assert np.array_equal(rgb, whole)
+    # a snapshot is the running sum after `done` strata, divided by done + 1: compare with a render of 4 of the
+    # 9 strata (same strata: recip_sqrt_spp and the stratum keys belong to samples=9, so stop a 9-sample render)
+    part, _, pst = rt.render_multi(o, devs[:3], rt.DeviceProgress(on_stratum=lambda d, t: d >= 4))
+    assert pst.strata == 4
+    want = rt.tonemap(part, 5).reshape(-1, 3)
+    assert np.array_equal(snaps[3][1], want)
+    # the 5-second rule: a render that takes less than min_interval never takes a snapshot
+    none = []
+    rt.render_multi(o, devs[:2], rt.DeviceProgress(on_snapshot=lambda d, t, img: none.append(d) and None, min_interval=5.0))
+    assert none == []
+    # one GPU, device buffers: the same protocol through rt_render_device_progress, snapshot in shard layout
+    import torch
+    from raytracer_amd import system
+    n = system.shard_pixels(o, 1, 3)
+    buf = torch.zeros(n * 3, dtype=torch.float64, device="cuda")
+    shots = []
+    devs[0].render_shard(o, 1, 3, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream,
+                         progress=rt.DeviceProgress(on_snapshot=lambda d, t, img: shots.append((d, img.copy())) and None,
+                                                    min_interval=0.0))
+    assert [d for d, _ in shots] == list(range(1, 9)) and shots[0][1].shape == (n, 3)
+    m = system.shard_map(o, 1, 3)
+    full4 = want.reshape(-1, 3)
+    assert np.array_equal(shots[3][1][m >= 0], full4[m[m >= 0]])
+    # FileRenderProgress: the reference's CliRenderProgress without the bar
+    from PIL import Image
+    fp = rt.FileRenderProgress(tmp_path / "out.png", 300, 200, min_interval=0.0)
+    rgb, _, st = rt.render_multi(o, devs[:2], fp)
+    fp.finish(rgb, st.strata)
+    assert fp.num_samples == 9 and fp.files_written == 9
+    with Image.open(tmp_path / "out.png") as im:
+        assert np.array_equal(np.asarray(im), rt.tonemap(whole, 10))
+
+
+def test_closed_mesh_with_large_grid_tables(rt, tmp_path):
+    """A closed surface of 16 000 triangles: occupancy words, distance nibbles, job records and the cell starts
+    of its grid together pass 64 KB, the most a workgroup may be given on some devices.  rt_scene_create checks
+    the tables against the device's limit and leaves the cell starts in memory when they do not fit (or
+    refuses the scene by name); either way the image is the oracle's."""
+    n_lat, n_lon = 90, 90
+    lines = ["o Ball"]
+    for i in range(n_lat + 1):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            p = (np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph))
+            lines.append("v %.9f %.9f %.9f" % p)
+            lines.append("vn %.9f %.9f %.9f" % p)
+    faces = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j + 1, i * n_lon + (j + 1) % n_lon + 1
+            c, d = a + n_lon, b + n_lon
+            faces.append("f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c))       # wound to face outwards
+            faces.append("f %d//%d %d//%d %d//%d" % (b, b, d, d, c, c))
+    (tmp_path / "ball.obj").write_text("\n".join(lines + ["s 1"] + faces) + "\n")
+    text = """options { background color rgb <0.5, 0.6, 0.8> }
+camera { origin <1.5, 1.2, 2.6> look_at <0, 0, 0> }
+object "floor" { plane { origin <0, -1, 0> normal <0, 1, 0> } material { lambertian texture { solid color rgb <0.7, 0.7, 0.6> } } }
+object "ball" { mesh { file "ball.obj" } material { metal fuzz 0.05 texture { solid color rgb <0.9, 0.8, 0.7> } } }
+"""
+    o = rt.Options(width=160, height=120, samples=1, seed=2, max_depth=6)
+    sc = rt.parse(o, text, str(tmp_path))
+    assert sc.desc.contents.n_triangles == 2 * n_lat * n_lon
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert (rids == 1).mean() > 0.2
+    rgb, ids, st = rt.DeviceScene(sc).render(o)
+    _check(parity.compare(rgb, ids, ref, rids, 1), st, rst)

@@ -257,3 +257,94 @@ def test_unsupported_and_invalid_descriptions(rt):
     rc = rt.lib.rt_scene_create(d.ptr, C.byref(h))
     assert rc == _capi.RT_ERR_INVALID and b"material" in rt.lib.rt_last_error()
     assert rt.lib.rt_scene_create(None, C.byref(h)) == _capi.RT_ERR_INVALID
+
+
+def _copy_desc(sc):
+    """A shallow copy of a parsed scene's rt_scene_desc whose mesh table is a private copy (so a test can damage it)."""
+    d = _capi.rt_scene_desc()
+    C.memmove(C.byref(d), sc.desc, C.sizeof(d))
+    meshes = (_capi.rt_mesh * d.n_meshes)()
+    C.memmove(meshes, d.meshes, C.sizeof(meshes))
+    d.meshes = C.cast(meshes, C.POINTER(_capi.rt_mesh))
+    return d, meshes
+
+
+def test_scene_create_rejects_mesh_ranges_outside_the_pools(rt):
+    """rt_scene_create validates what a host flatten pass hands over before anything is read through it: mesh
+    vertex / normal / triangle ranges inside the pools, composite children inside child_list, null arrays with
+    non-zero counts, the packed hit id's limits.  Bad descriptions come back as RT_ERR_INVALID / UNSUPPORTED with
+    a message - never a crash, never an exception across the C ABI.  (No GPU needed: validation comes first; a
+    valid description then fails with RT_ERR_DEVICE here.)"""
+    o = rt.Options(width=64, height=48)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    h = C.c_void_p()
+
+    def create(d):
+        rc = rt.lib.rt_scene_create(C.byref(d), C.byref(h))
+        if rc == 0:
+            rt.lib.rt_scene_destroy(h)
+        return rc, rt.lib.rt_last_error().decode()
+
+    d, meshes = _copy_desc(sc)
+    rc, msg = create(d)
+    assert rc in (0, _capi.RT_ERR_DEVICE), msg                     # the untouched copy is fine
+    for field, pool in (("n_vertices", "vertex"), ("n_normals", "normal"), ("n_triangles", "triangle")):
+        d, meshes = _copy_desc(sc)
+        setattr(meshes[0], field, getattr(meshes[0], field) + 10 ** 6)
+        rc, msg = create(d)
+        assert rc == _capi.RT_ERR_INVALID and pool in msg, (field, rc, msg)
+    for field in ("first_vertex", "first_normal", "first_triangle"):
+        d, meshes = _copy_desc(sc)
+        setattr(meshes[0], field, 0xFFFFFFF0)                      # first + count wraps in 32 bits
+        rc, msg = create(d)
+        assert rc == _capi.RT_ERR_INVALID, (field, rc, msg)
+    d, meshes = _copy_desc(sc)
+    d.n_child_list = 0                                             # the composite's children are gone
+    rc, msg = create(d)
+    assert rc == _capi.RT_ERR_INVALID and "child" in msg
+    d, meshes = _copy_desc(sc)
+    d.normals = None                                               # a count without an array
+    rc, msg = create(d)
+    assert rc == _capi.RT_ERR_INVALID and "normals" in msg
+    d, meshes = _copy_desc(sc)
+    d.n_triangles = d.n_triangles - 1                              # the pool is shorter than the mesh says
+    rc, msg = create(d)
+    assert rc == _capi.RT_ERR_INVALID and "triangle" in msg
+
+
+def test_options_limits(rt):
+    """check_options: the random-number key holds 16 bits of stratum and of depth, 32 of pixel."""
+    def rc_of(**kw):
+        o = rt.Options(width=64, height=64, **kw).to_c()
+        return rt.lib.rt_unshard_device(C.byref(o), 0, None, None, None, None, None)
+    ok = (0, _capi.RT_ERR_DEVICE)                  # the options pass; without a GPU the launch behind them fails
+    assert rc_of(samples=65536) in ok and rc_of(samples=65537) in ok      # floor(sqrt)^2 = 65536 strata: the last that fit
+    assert rc_of(samples=257 * 257) == _capi.RT_ERR_INVALID
+    assert b"strata" in rt.lib.rt_last_error()
+    assert rc_of(max_depth=65535) in ok and rc_of(max_depth=65536) == _capi.RT_ERR_INVALID
+
+
+def test_greyscale_jpeg_with_sampling_factors(rt, tmp_path):
+    """A one-component JPEG whose frame header says 2x2 sampling is still one 8x8 block per MCU in raster order
+    (T.81 A.2.2: a scan with one component is not interleaved).  PIL writes 1x1; the SOF0 sampling byte is
+    patched to 0x22 here, which changes nothing for a conforming decoder."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:45, 0:70]
+    img = (127 + 80 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 3, (45, 70))).clip(0, 255).astype(np.uint8)
+    Image.fromarray(img, "L").save(tmp_path / "grey.jpg", quality=92)
+    raw = bytearray((tmp_path / "grey.jpg").read_bytes())
+    k = raw.find(b"\xff\xc0")
+    assert k > 0 and raw[k + 9] == 1 and raw[k + 11] == 0x11          # SOF0, one component, sampling 1x1
+    raw[k + 11] = 0x22
+    (tmp_path / "grey22.jpg").write_bytes(bytes(raw))
+    with Image.open(tmp_path / "grey22.jpg") as im:
+        want = np.asarray(im.convert("RGB")).astype(int)
+    text = ('camera { origin <0, 0, 5> look_at <0, 0, 0> }\nobject { sphere { origin <0, 0, 0> radius 1 } '
+            'material { lambertian texture { image "grey22.jpg" 1.0 } } }\n')
+    o = rt.Options(width=16, height=16)
+    sc = rt.parse(o, text, str(tmp_path))
+    d = sc.desc.contents
+    assert d.n_images == 1 and d.images[0].width == 70 and d.images[0].height == 45
+    got = np.ctypeslib.as_array(d.image_data, shape=(d.n_image_bytes,))[:70 * 45 * 3].reshape(45, 70, 3).astype(int)
+    assert np.abs(got - want).max() <= 3 and np.abs(got - want).mean() < 0.5
