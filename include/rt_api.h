@@ -287,13 +287,13 @@ int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_option
 /* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same outputs (bit for
  * bit), but the wavefront state (ray queues, hit records, mesh queue, counters) lives in a static device
- * array of the library (87.8 MiB per GPU the library runs on, held until the process ends) instead of a
+ * array of the library (95.8 MiB per GPU the library runs on, held until the process ends) instead of a
  * workspace the scene allocates and grows, and the call makes no hipMalloc / hipFree / hipHostMalloc /
  * hipEventCreate: everything else it needs was set up by rt_scene_create.  Limits: a shard of at most
  * RT_NOALLOC_MAX_SLOTS ray slots (rt_shard_pixels(opts); 640 x 480 fits) and max_depth <=
  * RT_NOALLOC_MAX_DEPTH, beyond which it returns RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's
  * array: calls that overlap on one GPU (two streams, two scenes, two threads) race. */
-#define RT_NOALLOC_MAX_SLOTS (104u * 4096u)
+#define RT_NOALLOC_MAX_SLOTS (84u * 4096u)
 #define RT_NOALLOC_MAX_DEPTH 64u
 int rt_render_device_noalloc(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,
                              rt_stats *stats, void *stream);

@@ -16,7 +16,7 @@ RT_ERR_PARSE = -2
 RT_ERR_IO = -3
 RT_ERR_DEVICE = -4
 RT_ERR_UNSUPPORTED = -5
-RT_NOALLOC_MAX_SLOTS = 104 * 4096
+RT_NOALLOC_MAX_SLOTS = 84 * 4096
 RT_NOALLOC_MAX_DEPTH = 64
 
 (RT_SHAPE_SPHERE, RT_SHAPE_PLANE, RT_SHAPE_XYRECT, RT_SHAPE_XZRECT, RT_SHAPE_ZYRECT, RT_SHAPE_CUBE,

@@ -32,6 +32,72 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_capi.rt_stats) == 128
 
 
+def _c_layout():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import layout_table
+    return layout_table, layout_table.layout()
+
+
+def test_layout_contract_ctypes_rust_and_docs():
+    """The binding contract of the boundary: what the C compiler makes of every struct in include/rt_api.h
+    (tests/helpers/layout_probe.c: sizeof, offsetof) equals (1) the ctypes mirror this repository exercises,
+    (2) the #[repr(C)] declarations of the Rust crate under ffi/ (parsed here and laid out by the C rules, since
+    no Rust toolchain exists in this image), (3) the table printed in INTEGRATION.md."""
+    layout_table, lay = _c_layout()
+    # (1) ctypes
+    for name, s in lay.items():
+        ct = getattr(_capi, name)
+        assert C.sizeof(ct) == s["size"], name
+        assert [f[0] for f in ct._fields_] == list(s["fields"]), name
+        for f, (off, size) in s["fields"].items():
+            d = getattr(ct, f)
+            assert (d.offset, d.size) == (off, size), (name, f)
+    # (2) Rust: #[repr(C)] pub struct NAME { pub field: TYPE, ... }
+    with open(os.path.join(ROOT, "ffi", "src", "lib.rs")) as f:
+        rust = f.read()
+    prim = {"i32": (4, 4), "u32": (4, 4), "u64": (8, 8), "f64": (8, 8), "u8": (1, 1)}
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+) \{(.*?)\n\}", rust, re.S):
+        structs[m.group(1)] = re.findall(r"pub (\w+): ([^,\n]+),", m.group(2))
+
+    def size_align(ty):
+        ty = ty.strip()
+        if ty in prim:
+            return prim[ty]
+        if ty.startswith("*") or ty in ("rt_stratum_cb", "rt_snapshot_cb", "rt_progress_cb"):
+            return 8, 8                                      # pointers and Option<extern "C" fn>
+        arr = re.match(r"\[(\w+); (\d+)\]", ty)
+        if arr:
+            sz, al = size_align(arr.group(1))
+            return sz * int(arr.group(2)), al
+        fields = structs[ty]
+        off, al = 0, 1
+        for _, t in fields:
+            s, a = size_align(t)
+            off = (off + a - 1) // a * a + s
+            al = max(al, a)
+        return (off + al - 1) // al * al, al
+
+    for name, s in lay.items():
+        assert name in structs, "ffi/src/lib.rs lacks %s" % name
+        assert [f for f, _ in structs[name]] == list(s["fields"]), name
+        off = 0
+        for f, t in structs[name]:
+            sz, al = size_align(t)
+            off = (off + al - 1) // al * al
+            assert [off, sz] == s["fields"][f], (name, f, off, sz)
+            off += sz
+        assert size_align(name)[0] == s["size"], name
+    # every function of the header is declared in the crate's extern block
+    for fn in _capi.SIGNATURES:
+        assert re.search(r"pub fn %s\(" % fn, rust), fn
+    # (3) the table in INTEGRATION.md
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    assert layout_table.table(lay) in doc, "INTEGRATION.md's layout table is stale: python tools/layout_table.py"
+
+
 # SURVEY appendix A: objects per scene, in file order
 EXPECTED_OBJECTS = {"three-spheres": 11, "cornell_box": 8, "mesh": 3, "torus": 3, "csg": 3, "cylinder": 4,
                     "transformations": 3, "room": 5, "fog_light": 5}
