@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warmup and the timed region only (the command the rocprofv3 summaries under profiles/ are taken of)")
+    ap.add_argument("--in-flight", type=int, default=3, help="independent frames a rank keeps in flight (1: one after the other)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (with --same-device) rehearses the multi-rank path on a one-GPU box: shards are gathered through host memory")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -158,36 +161,62 @@ def main():
     opts = rt.Options(width=args.width, height=args.height, samples=args.samples, seed=1)
     scene = rt.parse_file(opts, os.path.join(ROOT, "tests", "assets", "scenes", args.scene + ".scene"),
                           os.path.join(ROOT, "tests", "assets"))
-    dscene = rt.DeviceScene(scene)  # scene upload: outside the timed region
-
+    # Frames in flight: consecutive steps are independent frames, so a rank keeps F of them going, each from its
+    # own host thread on its own stream with its own resident copy of the scene and its own output buffer.  One
+    # frame alone leaves the GPU idle through its late bounce passes (a few thousand rays each), its tail kernel
+    # and the host's queue-length read-backs; the next frame's full passes fill those gaps.  Gathers stay in step
+    # order on the main thread (a collective must be issued in the same order on every rank).
+    import dataclasses
+    from concurrent.futures import ThreadPoolExecutor
+    F = max(1, args.in_flight)
     n_slots = [system.shard_pixels(opts, r, world) for r in range(world)]
     max_slots = max(n_slots)
-    shard = torch.zeros(max_slots * 3, dtype=torch.float64, device=dev) if world > 1 else None
-    full = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if rank == 0 else None
+    full = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
     gathered = [torch.zeros(max_slots * 3, dtype=torch.float64, device=dev) for _ in range(world)] \
         if (rank == 0 and world > 1) else None
-    stream = torch.cuda.current_stream().cuda_stream
+    slots = []
+    for f in range(F):  # scene upload and buffers: outside the timed region
+        out = torch.zeros((max_slots if world > 1 else args.height * args.width) * 3, dtype=torch.float64, device=dev)
+        slots.append({"scene": rt.DeviceScene(scene), "stream": torch.cuda.Stream(device=dev), "out": out})
+    main_stream = torch.cuda.current_stream().cuda_stream
+    pool = ThreadPoolExecutor(F)
 
-    def step(k):
-        opts.seed = 1 + k
-        if world > 1:
-            st = dscene.render_shard(opts, rank, world, shard.data_ptr(), None, stream)
-            if args.backend == "nccl":
-                dist.gather(shard, gathered, dst=0)
-            else:
-                host = shard.cpu()
-                parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, parts, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        gathered[r].copy_(parts[r])
+    def render(k, instrumented):
+        slot = slots[k % F]
+        o = dataclasses.replace(opts, seed=1 + k, stage_times=instrumented)
+        torch.cuda.set_device(local_rank)
+        # a single GPU writes the row-major image directly (RT_FLAG_ROW_MAJOR): nothing to reassemble
+        return slot["scene"].render_shard(o, rank, world, slot["out"].data_ptr(), None, slot["stream"].cuda_stream,
+                                          row_major=(world == 1))
+
+    def exchange(k):
+        """the one exchange step of frame k: every rank's tiles to rank 0, scattered into the row-major image"""
+        shard = slots[k % F]["out"]
+        if args.backend == "nccl":
+            dist.gather(shard, gathered, dst=0)
+        else:
+            host = shard.cpu()
+            parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
             if rank == 0:
                 for r in range(world):
-                    system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=stream)
-        else:
-            # a single GPU writes the row-major image directly (RT_FLAG_ROW_MAJOR): nothing to reassemble
-            st = dscene.render_shard(opts, 0, 1, full.data_ptr(), None, stream, row_major=True)
-        return st
+                    gathered[r].copy_(parts[r])
+        if rank == 0:
+            for r in range(world):
+                system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=main_stream)
+        torch.cuda.current_stream().synchronize()  # the slot's buffer is free for frame k + F
+
+    def run(first, count, instrumented):
+        """steps first .. first + count - 1, F of them in flight; returns their rt_stats in step order"""
+        futs = {k: pool.submit(render, k, instrumented) for k in range(first, first + min(F, count))}
+        stats = []
+        for k in range(first, first + count):
+            stats.append(futs.pop(k).result())
+            if world > 1:
+                exchange(k)
+            if k + F < first + count:
+                futs[k + F] = pool.submit(render, k + F, instrumented)
+        return stats
 
     def barrier():
         torch.cuda.synchronize()
@@ -198,47 +227,50 @@ def main():
     # The timed region runs with the per-kernel HIP events on (RT_FLAG_STAGE_TIMES): the roofline figure must
     # come from events on the launch stream inside it.  They cost about 3 % of the frame; `uninstrumented`
     # repeats the same steps without them.
-    opts.stage_times = True
-    for k in range(args.warmup):
-        step(k)
+    run(0, args.warmup, True)
     barrier()
     t0 = time.perf_counter()
-    rays = 0
-    acc = dict(ms_int=0.0, ms_mesh=0.0, ms_shade=0.0, ms_tail=0.0, ms_raygen=0.0, n_int=0, n_mesh=0, int_rays=0,
-               mesh_rays=0, mesh_records=0)
-    for k in range(args.steps):
-        st = step(args.warmup + k)
-        rays += st.rays
-        acc["ms_int"] += st.ms_intersect
-        acc["ms_mesh"] += st.ms_mesh
-        acc["ms_shade"] += st.ms_shade
-        acc["ms_tail"] += st.ms_tail
-        acc["ms_raygen"] += st.ms_raygen
-        acc["n_int"] += st.n_intersect_launches
-        acc["n_mesh"] += st.n_mesh_launches
-        acc["int_rays"] += st.intersect_rays
-        acc["mesh_rays"] += st.mesh_rays
-        acc["mesh_records"] += st.mesh_records
+    stats = run(args.warmup, args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
-    opts.stage_times = False
-    step(0)
-    barrier()
-    t1 = time.perf_counter()
-    rays_plain = 0
-    for k in range(args.steps):
-        rays_plain += step(args.warmup + k).rays
-    barrier()
-    dt_plain = time.perf_counter() - t1
+    rays = sum(st.rays for st in stats)
+    acc = dict(ms_int=sum(st.ms_intersect for st in stats), ms_mesh=sum(st.ms_mesh for st in stats),
+               ms_shade=sum(st.ms_shade for st in stats), ms_tail=sum(st.ms_tail for st in stats),
+               ms_raygen=sum(st.ms_raygen for st in stats), n_int=sum(st.n_intersect_launches for st in stats),
+               n_mesh=sum(st.n_mesh_launches for st in stats), int_rays=sum(st.intersect_rays for st in stats),
+               mesh_rays=sum(st.mesh_rays for st in stats), mesh_records=sum(st.mesh_records for st in stats))
+    if args.timed_only:
+        dt_plain = dt
+    else:
+        run(0, min(F, args.steps), False)
+        barrier()
+        t1 = time.perf_counter()
+        run(args.warmup, args.steps, False)
+        barrier()
+        dt_plain = time.perf_counter() - t1
+    # one frame at a time (no overlap): the latency of a frame, and per-kernel times that no other frame shares
+    if F > 1 and not args.timed_only:
+        F_saved, F = F, 1
+        run(0, 1, True)
+        barrier()
+        t2 = time.perf_counter()
+        alone = run(args.warmup, args.steps, True)
+        barrier()
+        dt_alone = time.perf_counter() - t2
+        F = F_saved
+    else:
+        alone, dt_alone = stats, dt
+    pool.shutdown()
 
     if world > 1:
-        t = torch.tensor([dt, float(rays), dt_plain], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([dt, float(rays), dt_plain, dt_alone], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         dt_plain = float(tmax[2])
+        dt_alone = float(tmax[3])
         rays_total = float(tsum[1])
     else:
         rays_total = float(rays)
@@ -274,8 +306,14 @@ def main():
         roof = dict(kernels[0])
         roof["traffic"] = traffic
         roof["traffic_source"] = traffic_note
-        roof["note"] = ("ms_mesh is the k_mesh + k_mesh_brute stage; k_mesh is a latency-bound grid walk, its HBM "
-                        "fraction is low by construction (DESIGN.md)")
+        roof["note"] = ("ms_mesh is the k_mesh + k_mesh_brute stage, HIP events of the timed region: with %d frames in flight a "
+                        "launch shares the GPU with the other frames' kernels while it runs; `one_frame_at_a_time` holds the "
+                        "same figure with the GPU to itself.  k_mesh is bound by VALU issue at low lane occupancy, not by HBM "
+                        "(DESIGN.md): its HBM fraction is low by construction" % F)
+        ms_mesh_alone = sum(st.ms_mesh for st in alone)
+        mesh_rays_alone = sum(st.mesh_rays for st in alone)
+        n_mesh_alone = sum(st.n_mesh_launches for st in alone)
+        rays_alone = sum(st.rays for st in alone) * (world if world > 1 else 1)  # (rank 0's share times ranks: an estimate for N > 1)
         frame_bytes = rays_total * BYTES_PER_RAY_FRAME + args.width * args.height * args.samples * BYTES_PER_PIXEL_SAMPLE * args.steps
         out = {
             "metric": "Mrays/sec (primary+secondary) at 4K, mesh.scene",
@@ -284,12 +322,16 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s.scene %dx%d samples=%d max_depth=50, seed=1+step" %
                                    (args.scene, args.width, args.height, args.samples),
-                       "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps},
+                       "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps,
+                       "frames_in_flight": F},
             "roofline": roof,
             "kernels": kernels[1:],
             # the same K steps again without the per-kernel events of the timed region (what rt_render costs a caller
             # that does not ask for stage times)
             "uninstrumented": {"value": rays_total / dt_plain / 1e6, "unit": "Mrays/s", "ms_per_step": dt_plain / args.steps * 1e3},
+            # the same K steps one frame after the other: the latency of a frame, and k_mesh with the GPU to itself
+            "one_frame_at_a_time": {"ms_per_step": dt_alone / args.steps * 1e3, "value": rays_alone / dt_alone / 1e6, "unit": "Mrays/s",
+                                    "k_mesh": line("k_mesh", mesh_rays_alone, BYTES_PER_RAY_MESH, ms_mesh_alone, n_mesh_alone)},
             "stage_ms_per_step": {"raygen": acc["ms_raygen"] / args.steps, "intersect": acc["ms_int"] / args.steps,
                                   "mesh": acc["ms_mesh"] / args.steps, "shade": acc["ms_shade"] / args.steps,
                                   "tail": acc["ms_tail"] / args.steps},

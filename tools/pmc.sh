@@ -9,7 +9,7 @@ n=0
 for set in "$@"; do
   n=$((n+1))
   out=gpurun_out/pmc_${tag}_$n
-  timeout -s KILL 150 rocprofv3 --pmc $set --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 $PMC_ARGS > $out.log 2>&1 || { echo "pass $n failed"; tail -5 $out.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $set --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --timed-only --in-flight 1 --steps 1 --warmup 1 $PMC_ARGS > $out.log 2>&1 || { echo "pass $n failed"; tail -5 $out.log; exit 1; }
   f=$(find $out -name "*counter_collection.csv" | head -1)
   cp $f $out.csv
   echo "pass $n: $(wc -l < $out.csv) rows -> $out.csv"

@@ -2,7 +2,7 @@
 # usage: tools/prof.sh <tag> [bench args...]  -> gpurun_out/prof_<tag>/ kernel stats (run on the GPU box)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/prof_$tag.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline --timed-only "$@" > gpurun_out/prof_$tag.log 2>&1
 rc=$?
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/prof_${tag}_kernel_stats.csv
