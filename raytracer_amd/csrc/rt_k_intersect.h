@@ -87,22 +87,24 @@ RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 
     return pick_from_list(res, ob.mode);
 }
 
-// Does the ray need the walk through a mesh of this object?  It must pass the Mesh::new box
-// (mesh.rs:32-42,117: no box hit, no intersection) and enter the triangles' own bounds before
-// the nearest hit found among the other objects (`have_hit`, `best_t`; slack keeps ties in play).
+// Does the ray need the walk through a mesh of this object?  Only a conservative answer is wanted here (k_mesh
+// applies the reference's own tests, mesh.rs:32-42,117, to every ray it is handed): the ray must enter the
+// padded bounds of the mesh's triangles at t >= 0 and before the nearest hit found among the other objects
+// (`have_hit`, `best_t`; slack keeps ties in play).  Those bounds lie inside the Mesh::new box, so a ray that
+// misses them meets no triangle.  The object-space direction is left un-normalised: the slab parameters are
+// then the world ray's own, no square root, no division beyond the three reciprocals.
 RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 d, bool have_hit, double best_t)
 {
     const DevLeaf &F = sc.leaves[ob.frame];
-    LeafRay ry = to_leaf(F, o, d);
-    d3 inv = mk3(1.0 / ry.d.x, 1.0 / ry.d.y, 1.0 / ry.d.z);
-    // object-space length per unit of world length (d need not have unit length: rt_trace_rays)
-    const double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d)) / len3(d);
-    const double bound = have_hit ? best_t * scale * (1.0 + 1e-7) + 1e-7 : 1.0e300;
+    const d3 ol = F.identity ? o : xf_point(F.W, o);
+    const d3 dl = F.identity ? d : xf_dir(F.W, d);
+    const d3 inv = mk3(1.0 / dl.x, 1.0 / dl.y, 1.0 / dl.z);
+    const double bound = have_hit ? best_t * (1.0 + 1e-7) + 1e-7 : 1.0e300;
     bool any = false;
     for (int mi = 0; mi < ob.n_meshes; ++mi) {
         const DevMesh &m = sc.meshes[ob.mesh0 + mi];
         double t0, t1;
-        any = any || (mesh_box_hit(m, ry.o, inv) && mesh_clip(m, ry.o, inv, t0, t1) && t0 <= bound);
+        any = any || (mesh_clip(m, ol, inv, t0, t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0));
     }
     return any;
 }
