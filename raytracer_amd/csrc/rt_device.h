@@ -124,6 +124,8 @@ struct DevMesh {
     uint32_t grp0, n_groups;
     uint32_t kd0;       // root node of this mesh's kd-tree (node indices inside it are mesh-relative)
     uint32_t kd_index0; // base of this mesh's leaf-ordered triangle records
+    uint32_t use_kd;    // this mesh is walked through its kd-tree (k_mesh<KD = true>), not its grid
+    float crowd;        // triangles in the cell of an average (cell, triangle) reference of its grid
 };
 
 // One (mesh object, mesh) pair, in the order Ray::trace / Composite::intersect would visit them:
@@ -138,7 +140,7 @@ struct DevMeshJob {
     uint32_t bits0, cell0, dist0;
     uint32_t tri0;    // into tris / tri_nrm
     uint32_t kd0, kd_index0;
-    uint32_t pad;
+    uint32_t use_kd;  // walked by k_mesh<KD = true>; the other instantiation passes this job by
     DevXform W, O;    // the object's frame: world -> object, object -> world
     double qmin[3], qmax[3];
     double bmin[3], bmax[3];

@@ -680,6 +680,11 @@ struct Flattener {
                 n2 += (double)cells[c].size() * (double)cells[c].size();
             }
             if (n1 > 0.0) out.grid_crowd = std::fmax(out.grid_crowd, n2 / n1);
+            // Structure per mesh.  The grid is the default (no stack, LDS-resident tables); it degrades when a
+            // mesh crowds many triangles into few cells, which the tree's SAH splits handle.
+            // LinkedTorus.obj: 7; Monkey.obj: 5; a "teapot in a stadium": 250.
+            dm.crowd = n1 > 0.0 ? (float)(n2 / n1) : 0.f;
+            dm.use_kd = dm.crowd > 24.f ? 1u : 0u;
         }
         if (out.grid_bits.size() / 2 > DEV_GRID_MAX_WORDS) throw Err{RT_ERR_UNSUPPORTED, "mesh grids exceed the device budget"};
         // Groups of 64 triangles that lie together (Morton order of the centroids) with their padded
@@ -958,6 +963,7 @@ int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
                 j.tri0 = m.tri0;
                 j.kd0 = m.kd0;
                 j.kd_index0 = m.kd_index0;
+                j.use_kd = m.use_kd;
                 j.W = F.W;
                 j.O = F.O;
                 out.jobs.push_back(j);

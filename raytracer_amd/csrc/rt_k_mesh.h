@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                         obj_found = false;
                     }
                     const DevMeshJob &J = JOB(jb);
+                    if ((J.use_kd != 0u) != KD) continue; // the other instantiation's mesh (structure per mesh)
                     const d3 inv = mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
                     if (!box_hit(J.qmin, J.qmax, o, inv)) continue;
                     double t0, t1;

@@ -112,7 +112,7 @@ struct rt_scene {
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
     uint64_t n_mesh_tris = 0;
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
-    bool mesh_kd = false;           // walk kd-trees instead of grids (chosen in rt_scene_create)
+    bool any_grid = false, any_kd = false; // (object, mesh) jobs walked through grids / through kd-trees
     uint32_t mesh_kd_lds_bytes = 0; // dynamic LDS of k_mesh<KD>: job records + stacks
     uint32_t host_depth_cap = 0;  // max_depth the pinned buffer and the events below are sized for
     uint32_t *h_pinned = nullptr; // readback slot
@@ -259,6 +259,20 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     // scene's pinned words and events for the deepest path that entry point accepts
     if ((rc = noalloc_setup(s->device))) return fail(rc);
     if ((rc = ensure_host_side(s, RT_NOALLOC_MAX_DEPTH))) return fail(rc);
+    {
+        // Structure per mesh, chosen by the flattener from how the mesh fills its grid (DevMesh::use_kd).
+        // RT_ACCEL=grid|kd overrides it for every mesh (measurements, tests).
+        if (const char *e = getenv("RT_ACCEL")) {
+            const int force = !strcmp(e, "kd") ? 1 : (!strcmp(e, "grid") ? 0 : -1);
+            if (force >= 0) {
+                for (DevMesh &m : flat.meshes) m.use_kd = (uint32_t)force;
+                for (DevMeshJob &j : flat.jobs) j.use_kd = (uint32_t)force;
+            }
+        }
+        for (const DevMeshJob &j : flat.jobs) (j.use_kd ? s->any_kd : s->any_grid) = true;
+        for (const DevMesh &m : flat.meshes)
+            RT_TRACE("mesh structure: %s (a triangle shares its grid cell with %.1f on average)", m.use_kd ? "kd-tree" : "grid", (double)m.crowd);
+    }
     if ((rc = upload(s, flat.objects, &s->dev.objects))) return fail(rc);
     if ((rc = upload(s, flat.leaves, &s->dev.leaves))) return fail(rc);
     if ((rc = upload(s, flat.prog, &s->dev.prog))) return fail(rc);
@@ -279,18 +293,6 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     if ((rc = upload(s, flat.leaf_tris, &s->dev.leaf_tris))) return fail(rc);
     s->mesh_kd_lds_bytes = (uint32_t)(std::min<size_t>(flat.jobs.size(), DEV_MESH_JOBS_LDS) * sizeof(DevMeshJob)) +
                            DEV_KD_STACK * RT_MESH_LANES * (uint32_t)sizeof(uint2);
-    {
-        // Structure per scene.  The grid is the default (same speed on LinkedTorus.obj, no stack, a
-        // trivial builder); it degrades when a mesh crowds many triangles into few cells, which the
-        // tree's SAH splits handle.  RT_ACCEL=grid|kd overrides (measurements, tests).
-        const double crowd = flat.grid_crowd; // triangles in the cell of an average (cell, triangle) reference, worst mesh
-        s->mesh_kd = crowd > 24.0;            // LinkedTorus.obj: 7; Monkey.obj: 5
-        if (const char *e = getenv("RT_ACCEL")) {
-            if (!strcmp(e, "kd")) s->mesh_kd = true;
-            if (!strcmp(e, "grid")) s->mesh_kd = false;
-        }
-        RT_TRACE("mesh structure: %s (a triangle shares its grid cell with %.1f on average)", s->mesh_kd ? "kd-tree" : "grid", crowd);
-    }
     {
         // dynamic LDS of k_mesh: job records, occupancy words, distance nibbles and - when they still fit the
         // device's per-workgroup limit - the cell starts
@@ -462,16 +464,19 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
 #define LAUNCH_M(KD, JL, LDS_BYTES)                                                                                    \
     hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, w.mq,        \
                        mesh_count, w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
-            if (s->mesh_kd) {
-                if (jobs_lds)
-                    LAUNCH_M(true, true, s->mesh_kd_lds_bytes);
-                else
-                    LAUNCH_M(true, false, s->mesh_kd_lds_bytes);
-            } else {
+            // one launch per structure in use: each instantiation walks its own meshes and passes the others by
+            // (the record carries the nearest hit from one launch to the next)
+            if (s->any_grid) {
                 if (jobs_lds)
                     LAUNCH_M(false, true, s->mesh_lds_bytes);
                 else
                     LAUNCH_M(false, false, s->mesh_lds_bytes);
+            }
+            if (s->any_kd) {
+                if (jobs_lds)
+                    LAUNCH_M(true, true, s->mesh_kd_lds_bytes);
+                else
+                    LAUNCH_M(true, false, s->mesh_kd_lds_bytes);
             }
 #undef LAUNCH_M
             walked = 1;

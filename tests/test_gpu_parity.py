@@ -817,3 +817,47 @@ object "ball" { mesh { file "ball.obj" } material { metal fuzz 0.05 texture { so
     assert (rids == 1).mean() > 0.2
     rgb, ids, st = rt.DeviceScene(sc).render(o)
     _check(parity.compare(rgb, ids, ref, rids, 1), st, rst)
+
+
+def test_structure_is_chosen_per_mesh(rt, tmp_path, monkeypatch):
+    """A crowded mesh (the stadium of test_crowded_mesh_teapot_in_a_stadium: kd-tree) beside an ordinary one
+    (LinkedTorus.obj: grid) in one scene: each is walked through its own structure, k_mesh<grid> and k_mesh<kd>
+    run one after the other over the same records, and the image is the oracle's - and bit for bit the image
+    with either structure forced on every mesh."""
+    import shutil
+    rng = np.random.default_rng(3)
+    lines = ["o Stadium", "v -30 0 -30", "v 30 0 -30", "v 30 0 30", "v -30 0 30", "vn 0 1 0"]
+    faces = ["f 1//1 3//1 2//1", "f 1//1 4//1 3//1"]
+    nv = 4
+    for _ in range(1500):
+        c = np.array([0.0, 0.4, 0.0]) + rng.uniform(-0.15, 0.15, 3)
+        p = c + rng.uniform(-0.03, 0.03, (3, 3))
+        for q in p:
+            lines.append("v %.6f %.6f %.6f" % tuple(q))
+        faces.append("f %d//1 %d//1 %d//1" % (nv + 1, nv + 2, nv + 3))
+        nv += 3
+    (tmp_path / "stadium.obj").write_text("\n".join(lines + ["s 1"] + faces) + "\n")
+    shutil.copy(os.path.join(parity.ASSETS, "LinkedTorus.obj"), tmp_path / "LinkedTorus.obj")
+    text = """options { background color rgb <0.4, 0.5, 0.7> }
+camera { origin <1.8, 1.6, 3.4> look_at <0.6, 0.5, 0> }
+object "light" { sphere { origin <4, 6, 3> radius 2 } material { diffuse_light intensity 4 texture { solid color white } } }
+object "stadium" { mesh { file "stadium.obj" } material { lambertian texture { solid color rgb <0.8, 0.6, 0.4> } } }
+object "tori" { mesh { file "LinkedTorus.obj" transform { scale <0.4, 0.4, 0.4> translate <1.3, 0.6, 0> } } material { metal fuzz 0.1 texture { solid color rgb <0.9, 0.9, 0.7> } } }
+"""
+    o = rt.Options(width=240, height=180, samples=1, seed=2)
+    sc = rt.parse(o, text, str(tmp_path))
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert (rids == 1).mean() > 0.3 and (rids == 2).mean() > 0.015
+    images = []
+    for accel in (None, "grid", "kd"):
+        if accel:
+            monkeypatch.setenv("RT_ACCEL", accel)
+        dev = rt.DeviceScene(sc)
+        rgb, ids, st = dev.render(o)
+        _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
+        images.append(rgb)
+        ro, rd = _random_rays(90000, 8, np.array([0.6, 0.5, 0.0]), 2.0)     # long queue: the walks, not the wave-per-ray kernel
+        got, _ = dev.trace_rays(ro, rd, seed=4)
+        want, _ = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
+        assert (got["object"] == want["object"]).mean() >= ID_MATCH_MIN
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[1], images[2])
