@@ -861,3 +861,17 @@ object "tori" { mesh { file "LinkedTorus.obj" transform { scale <0.4, 0.4, 0.4> 
         want, _ = oracle_lib.trace_rays(sc.desc, ro, rd, seed=4)
         assert (got["object"] == want["object"]).mean() >= ID_MATCH_MIN
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[1], images[2])
+
+
+def test_complex_v2_hand_translation(rt):
+    """complex_v2.scene: the reference's complex.scene translated by hand into the grammar the reference parses
+    today (the original is in an obsolete dialect that the reference itself rejects; the file's header lists the
+    choices made).  Not a reference input - a stress case: a closed room (paths run to the depth cap), a mesh, an
+    image texture, metal and glass, 14 objects."""
+    o = rt.Options(width=200, height=150, samples=4, seed=3)
+    sc = rt.parse_file(o, parity.scene_path("complex_v2"), parity.ASSETS)
+    assert sc.n_objects == 14
+    rgb, ids, st = rt.render(o, sc)
+    ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert {8, 9, 10, 11, 12, 13} <= set(np.unique(rids).tolist())     # earth, tori, the three spheres, the glass ball
+    _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)

@@ -9,6 +9,7 @@ run --scene torus --width 3840 --height 2160 --steps 5 --warmup 1
 run --scene csg --width 3840 --height 2160 --steps 5 --warmup 1
 run --scene three-spheres --width 3840 --height 2160 --steps 5 --warmup 1
 run --scene room --width 3840 --height 2160 --steps 3 --warmup 1
+run --scene complex_v2 --width 3840 --height 2160 --steps 3 --warmup 1
 run --scene fog_light --width 7680 --height 4320 --samples 16 --steps 1 --warmup 1
 python - <<'PY'
 import json
