@@ -145,6 +145,7 @@ struct DevMeshJob {
     double qmin[3], qmax[3];
     double bmin[3], bmax[3];
     double inv_cell[3];
+    double cell[3];
 };
 
 struct DevMaterial {
@@ -169,7 +170,9 @@ struct DevScene {
     const uint32_t *grid_dist;  // distance nibbles of every mesh grid, 8 cells per word
     const uint32_t *cell_start; // per mesh: occupied cells + 1 offsets into cell_tris (absolute record indices)
     const double *tris;      // 9 per triangle
-    const double *cell_tris; // 10 per (cell, triangle) reference, in cell order: the 9 above + the triangle index (low word)
+    const double *cell_tris; // 10 per (cell, triangle) reference, in cell order: the 9 above + the triangle index (low word);
+                             // runs padded to an even length (index ~0u)
+    const float *cell_pairs; // 20 per two entries of cell_tris: v0 - cell centre, e1, e2, error bound, each as (A, B) in f32
     const uint32_t *tri_n; // 3 per triangle (normal indices, mesh-relative)
     const double *tri_nrm; // 9 per triangle: its three vertex normals
     const DevKdNode *kd;     // kd-trees of all meshes

@@ -664,12 +664,66 @@ struct Flattener {
             if (cells[c].empty()) continue;
             out.cell_start.push_back((uint32_t)(out.cell_tris.size() / 10));
             // cell-ordered copies of the triangle records: a cell's triangles are one contiguous
-            // run, with no index indirection in the walk's dependent-load chain
+            // run, with no index indirection in the walk's dependent-load chain.  Runs are padded to an
+            // even length (the f32 pre-test below takes two records at a time).
+            const size_t run0 = out.cell_tris.size() / 10;
             for (uint32_t t : cells[c]) {
                 for (int k = 0; k < 9; ++k) out.cell_tris.push_back(out.tris[((size_t)dm.tri0 + t) * 9 + k]);
                 double tag = 0.0;
                 std::memcpy(&tag, &t, sizeof(t));
                 out.cell_tris.push_back(tag);
+            }
+            if (cells[c].size() & 1u) {
+                const uint32_t none = 0xFFFFFFFFu;
+                double tag = 0.0;
+                std::memcpy(&tag, &none, sizeof(none));
+                for (int k = 0; k < 9; ++k) out.cell_tris.push_back(0.0);
+                out.cell_tris.push_back(tag);
+            }
+            // The same run as f32 pairs for k_mesh's conservative pre-test: 20 floats per two records, component
+            // by component (A, B): v0 relative to the cell's centre (both operands of o - v0 are then small, so
+            // is their rounding), e1, e2, and the record's error bound delta.  In exact arithmetic a hit has
+            // det > 0, 0 <= un <= det, vn >= 0, un + vn <= det (mesh.rs:76-92 times det).  Evaluated in f32 from
+            // inputs rounded to f32, un and vn (three products of a component of o - v0 (|.| <= R), one of an
+            // edge (<= E) and one of the unit direction, summed over six terms with fused multiply-adds) are off
+            // by less than 60 eps E R and det by less than 48 eps E^2 (eps = 2^-24); delta = 128 eps E (R + E)
+            // covers either with a factor two to spare.  R: farthest corner of the padded cell from v0 (the
+            // ray's entry point into the cell is the other operand), E: the longer edge.
+            const size_t cz = c / ((size_t)dm.n[0] * dm.n[1]), cy = (c / dm.n[0]) % dm.n[1], cx = c % dm.n[0];
+            const size_t idx3[3] = {cx, cy, cz};
+            double centre[3], half[3];
+            for (int k = 0; k < 3; ++k) {
+                centre[k] = dm.bmin[k] + ((double)idx3[k] + 0.5) * dm.cell[k]; // k_mesh evaluates the same expression
+                half[k] = 0.5 * dm.cell[k] + 2.0 * pad;
+            }
+            const size_t n_run = out.cell_tris.size() / 10 - run0;
+            for (size_t r = 0; r < n_run; r += 2) {
+                float rec[20];
+                for (int side = 0; side < 2; ++side) {
+                    const double *q = &out.cell_tris[(run0 + r + side) * 10];
+                    uint32_t ti;
+                    std::memcpy(&ti, &q[9], sizeof(ti));
+                    if (ti == 0xFFFFFFFFu) { // the padding record: fails every comparison
+                        for (int k = 0; k < 9; ++k) rec[2 * k + side] = 0.f;
+                        rec[18 + side] = -3.0e38f;
+                        continue;
+                    }
+                    double E = 0.0, R = 0.0;
+                    for (int e = 0; e < 2; ++e) {
+                        const double *ev = q + 3 + 3 * e;
+                        E = std::fmax(E, std::sqrt(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]));
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        const double far = std::fabs(q[k] - centre[k]) + half[k];
+                        R += far * far;
+                    }
+                    R = std::sqrt(R) * (1.0 + 1e-6);
+                    for (int k = 0; k < 3; ++k) rec[2 * k + side] = (float)(q[k] - centre[k]);
+                    for (int k = 3; k < 9; ++k) rec[2 * k + side] = (float)q[k];
+                    const double delta = 128.0 * 5.9604644775390625e-08 * E * (R + E) * 1.01 + 1e-37;
+                    rec[18 + side] = (float)delta >= delta ? (float)delta : std::nextafterf((float)delta, 3.0e38f);
+                }
+                out.cell_pairs.insert(out.cell_pairs.end(), rec, rec + 20);
             }
         }
         out.cell_start.push_back((uint32_t)(out.cell_tris.size() / 10));
@@ -956,6 +1010,7 @@ int flatten_scene(const rt_scene_desc *desc, FlatScene &out, std::string &err)
                     j.bmin[a] = m.bmin[a];
                     j.bmax[a] = m.bmax[a];
                     j.inv_cell[a] = m.inv_cell[a];
+                    j.cell[a] = m.cell[a];
                 }
                 j.bits0 = m.bits0;
                 j.cell0 = m.cell0;

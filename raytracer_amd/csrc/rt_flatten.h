@@ -18,6 +18,7 @@ struct FlatScene {
     std::vector<uint32_t> cell_start;
     std::vector<double> tris;
     std::vector<double> cell_tris;
+    std::vector<float> cell_pairs; // 20 per two entries of cell_tris: the f32 pre-test records of k_mesh
     std::vector<uint32_t> tri_n;
     std::vector<double> tri_nrm;
     std::vector<DevMeshJob> jobs;

@@ -63,7 +63,7 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
 // Waves take blocks of 64 queue entries, interleaved; with more than one block per
 // wave (large queues) a wave refills its finished lanes once `refill` of them are idle.
 #ifdef RT_MESH_PROF
-__device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, services, lanes walking, lanes testing, waves
+__device__ unsigned long long g_pf[14]; // cycles: service, walk, test; rounds, services, lanes walking, lanes testing, waves
 #endif
 // The walk state is kept in plain scalars (not an aggregate): selecting a field by axis
 // would otherwise be compiled into an indexed access to a copy in scratch memory.
@@ -116,6 +116,9 @@ __device__ unsigned long long g_pf[12]; // cycles: service, walk, test; rounds, 
 // the merge - is shared.  rt_scene_create picks the structure per scene.
 // JOBS_LDS: every job record is in LDS (at most DEV_MESH_JOBS_LDS of them).  A compile-time fact on purpose:
 // a run-time choice between the LDS copy and memory makes each field access a flat load.
+typedef float v2f __attribute__((ext_vector_type(2)));
+RT_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <bool KD, bool JOBS_LDS>
 __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q,
                                                       const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
 
 #ifdef RT_MESH_PROF
     long long pf_t = clock64(), pf_service = 0, pf_walk = 0, pf_test = 0, pf_n = 0, pf_a = 0, pf_b = 0, pf_c = 0, pf_d = 0;
-    unsigned long long pf_rounds = 0, pf_services = 0, pf_lanes_walk = 0, pf_lanes_test = 0, pf_tests = 0;
+    unsigned long long pf_rounds = 0, pf_services = 0, pf_lanes_walk = 0, pf_lanes_test = 0, pf_tests = 0, pf_hits = 0;
 #define PF_MARK(ACC) do { long long n_ = clock64(); ACC += n_ - pf_t; pf_t = n_; } while (0)
 #else
 #define PF_MARK(ACC) do { } while (0)
@@ -488,7 +491,6 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
             if (active && occupied) {
                 const uint2 gw = grid_lds[bits0 + (cell >> 5)];
 #ifdef RT_MESH_PROF
-                pf_tests += 0; // counted below per lane
 #endif
                 const uint32_t r = cell0 + gw.y + (uint32_t)__popc(gw.x & ((1u << (cell & 31u)) - 1u));
                 uint32_t first, last;
@@ -499,28 +501,58 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     first = sc.cell_start[r];
                     last = sc.cell_start[r + 1u];
                 }
-                // RT_MESH_BATCH records per step, all loaded before the first test: a step costs one
-                // round trip to memory (~2000 cycles for 64 lanes' scattered records) whatever it tests
-                const double2 *__restrict__ rec = reinterpret_cast<const double2 *>(sc.cell_tris + (size_t)first * 10);
-                for (uint32_t e = first; e < last; e += RT_MESH_BATCH, rec += 5 * RT_MESH_BATCH) {
-                    double2 r[RT_MESH_BATCH][5];
-#pragma unroll
-                    for (int b = 0; b < RT_MESH_BATCH; ++b) {
-                        const double2 *src = (e + (uint32_t)b < last) ? rec + 5 * b : rec; // past the end: repeat the first
-#pragma unroll
-                        for (int c = 0; c < 5; ++c) r[b][c] = src[c];
+                // Two stages per run of records.  (1) A conservative pre-test in f32, two records per step with
+                // packed instructions (v_pk_fma_f32: 41 VALU instructions per two triangles against 154 for the
+                // reference's f64 test): a record whose numerators fail by more than its error bound cannot be a
+                // hit; the others - 1 in 20 - set a bit.  (2) The reference's own f64 test (mesh.rs:66-113) for the
+                // records whose bit is set, from the f64 copy of the run.  Runs are padded to an even length; 32
+                // records per chunk (one mask word).
+                const DevMeshJob &J = JOB(jb);
+                // the ray's entry point into this cell relative to the cell's centre: the f32 records hold v0 - centre
+                const float fox = (float)((o.x + d.x * w_tc) - (J.bmin[0] + ((double)cx + 0.5) * J.cell[0]));
+                const float foy = (float)((o.y + d.y * w_tc) - (J.bmin[1] + ((double)cy + 0.5) * J.cell[1]));
+                const float foz = (float)((o.z + d.z * w_tc) - (J.bmin[2] + ((double)cz + 0.5) * J.cell[2]));
+                const v2f OX = {fox, fox}, OY = {foy, foy}, OZ = {foz, foz};
+                const v2f DX = {(float)d.x, (float)d.x}, DY = {(float)d.y, (float)d.y}, DZ = {(float)d.z, (float)d.z};
+                for (uint32_t base = first; base < last; base += 32u) {
+                    const uint32_t n = last - base < 32u ? last - base : 32u;
+                    uint32_t pend = 0u;
+                    const float4 *__restrict__ pr = reinterpret_cast<const float4 *>(sc.cell_pairs + (size_t)(base >> 1) * 20);
+                    for (uint32_t k = 0; k < n; k += 2u, pr += 5) {
+                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2], q3 = pr[3], q4 = pr[4];
+                        const v2f v0x = {q0.x, q0.y}, v0y = {q0.z, q0.w}, v0z = {q1.x, q1.y};
+                        const v2f e1x = {q1.z, q1.w}, e1y = {q2.x, q2.y}, e1z = {q2.z, q2.w};
+                        const v2f e2x = {q3.x, q3.y}, e2y = {q3.z, q3.w}, e2z = {q4.x, q4.y}, dl = {q4.z, q4.w};
+                        const v2f px = fma2(DY, e2z, -(DZ * e2y)), py = fma2(DZ, e2x, -(DX * e2z)), pz = fma2(DX, e2y, -(DY * e2x));
+                        const v2f det = fma2(e1z, pz, fma2(e1y, py, e1x * px));
+                        const v2f tx = OX - v0x, ty = OY - v0y, tz = OZ - v0z;
+                        const v2f un = fma2(tz, pz, fma2(ty, py, tx * px));
+                        const v2f qx = fma2(ty, e1z, -(tz * e1y)), qy = fma2(tz, e1x, -(tx * e1z)), qz = fma2(tx, e1y, -(ty * e1x));
+                        const v2f vn = fma2(DZ, qz, fma2(DY, qy, DX * qx));
+                        // det >= -dl, un >= -dl, vn >= -dl, det - un >= -2 dl, det - un - vn >= -3 dl
+                        const v2f m1 = det + dl, m2 = un + dl, m3 = vn + dl, m4 = (det - un) + 2.0f * dl, m5 = (m4 - vn) + dl;
+                        const v2f m = __builtin_elementwise_min(__builtin_elementwise_min(m1, m2),
+                                                                __builtin_elementwise_min(__builtin_elementwise_min(m3, m4), m5));
+                        pend |= ((m.x >= 0.f ? 1u : 0u) | (m.y >= 0.f ? 2u : 0u)) << k; // (a NaN fails: such a record...)
+                        // ... has NaN numerators in f64 as well (0 * inf from a degenerate ray or record) and is no hit there
                     }
-#pragma unroll
-                    for (int b = 0; b < RT_MESH_BATCH; ++b) {
-                        const d3 v0 = mk3(r[b][0].x, r[b][0].y, r[b][1].x), e1 = mk3(r[b][1].y, r[b][2].x, r[b][2].y),
-                                 e2 = mk3(r[b][3].x, r[b][3].y, r[b][4].x);
-                        const uint32_t ti = (uint32_t)__double2loint(r[b][4].y);
+                    const double2 *__restrict__ rec0 = reinterpret_cast<const double2 *>(sc.cell_tris + (size_t)base * 10);
+                    while (pend) {
+                        const uint32_t bsel = (uint32_t)__ffs((int)pend) - 1u;
+                        pend &= pend - 1u;
+                        const double2 *__restrict__ rec = rec0 + 5 * bsel;
+                        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+                        const d3 v0 = mk3(r0.x, r0.y, r1.x), e1 = mk3(r1.y, r2.x, r2.y), e2 = mk3(r3.x, r3.y, r4.x);
+                        const uint32_t ti = (uint32_t)__double2loint(r4.y);
                         double t, u, v;
-                        if (tri_hit_v(v0, e1, e2, o, d, t, u, v)) {
-                            if (t < mt || (t == mt && ti < mtri)) { // a repeated record cannot beat itself
-                                mt = t;
-                                mtri = ti;
-                            }
+                        const bool hit_ = tri_hit_v(v0, e1, e2, o, d, t, u, v);
+#ifdef RT_MESH_PROF
+                        ++pf_tests;
+                        pf_hits += hit_ ? 1u : 0u;
+#endif
+                        if (hit_ && (t < mt || (t == mt && ti < mtri))) {
+                            mt = t;
+                            mtri = ti;
                         }
                     }
                 }
@@ -547,6 +579,18 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
         atomicAdd(&g_pf[5], pf_lanes_walk);
         atomicAdd(&g_pf[6], pf_lanes_test);
         atomicAdd(&g_pf[7], 1ull);
+    }
+    {
+        // lane-level: triangle tests made, of which hits
+        unsigned long long tt = pf_tests, hh = pf_hits;
+        for (int off = 32; off >= 1; off >>= 1) {
+            tt += __shfl_xor(tt, off);
+            hh += __shfl_xor(hh, off);
+        }
+        if (lane_id() == 0) {
+            atomicAdd(&g_pf[12], tt);
+            atomicAdd(&g_pf[13], hh);
+        }
     }
 #endif
 }

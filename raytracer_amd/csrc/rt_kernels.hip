@@ -313,6 +313,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     }
     if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
     if ((rc = upload(s, flat.cell_tris, &s->dev.cell_tris))) return fail(rc);
+    if ((rc = upload(s, flat.cell_pairs, &s->dev.cell_pairs))) return fail(rc);
     if ((rc = upload(s, flat.tri_n, &s->dev.tri_n))) return fail(rc);
     if ((rc = upload(s, flat.normals, &s->dev.normals))) return fail(rc);
     if ((rc = upload(s, flat.materials, &s->dev.materials))) return fail(rc);
@@ -752,14 +753,15 @@ finished:
     local.strata = n_slots ? done : strata; // fewer than floor(sqrt(samples))^2 when the callback stopped the render
 #ifdef RT_MESH_PROF
     {
-        unsigned long long pf[12];
+        unsigned long long pf[14];
         (void)hipMemcpyFromSymbol(pf, HIP_SYMBOL(g_pf), sizeof(pf));
         fprintf(stderr, "[k_mesh] waves %llu: cycles/wave service %.0f walk %.0f test %.0f; rounds/wave %.1f services/wave %.1f; lanes walking/round %.1f testing/round %.1f\n",
                 pf[7], (double)pf[0] / pf[7], (double)pf[1] / pf[7], (double)pf[2] / pf[7], (double)pf[3] / pf[7],
                 (double)pf[4] / pf[7], (double)pf[5] / (double)pf[3], (double)pf[6] / (double)pf[3]);
         fprintf(stderr, "[k_mesh] service split: reload+merge %.0f fetch %.0f advance %.0f write %.0f\n", (double)pf[8] / pf[7],
                 (double)pf[9] / pf[7], (double)pf[10] / pf[7], (double)pf[11] / pf[7]);
-        unsigned long long z[12] = {0};
+        fprintf(stderr, "[k_mesh] triangle tests (lanes) %llu, hits %llu (%.1f %%)\n", pf[12], pf[13], 100.0 * (double)pf[13] / (double)(pf[12] ? pf[12] : 1));
+        unsigned long long z[14] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf), z, sizeof(z));
     }
 #endif
