@@ -29,6 +29,9 @@ struct HitBuf {
 #ifndef RT_MESH_BATCH
 #define RT_MESH_BATCH 2
 #endif
+#ifndef RT_MESH_PAIRS
+#define RT_MESH_PAIRS 2 // f32 record pairs k_mesh loads and pre-tests per step
+#endif
 #ifndef RT_MESH_WAVES
 #define RT_MESH_WAVES 3
 #endif

@@ -518,23 +518,36 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     const uint32_t n = last - base < 32u ? last - base : 32u;
                     uint32_t pend = 0u;
                     const float4 *__restrict__ pr = reinterpret_cast<const float4 *>(sc.cell_pairs + (size_t)(base >> 1) * 20);
-                    for (uint32_t k = 0; k < n; k += 2u, pr += 5) {
-                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2], q3 = pr[3], q4 = pr[4];
-                        const v2f v0x = {q0.x, q0.y}, v0y = {q0.z, q0.w}, v0z = {q1.x, q1.y};
-                        const v2f e1x = {q1.z, q1.w}, e1y = {q2.x, q2.y}, e1z = {q2.z, q2.w};
-                        const v2f e2x = {q3.x, q3.y}, e2y = {q3.z, q3.w}, e2z = {q4.x, q4.y}, dl = {q4.z, q4.w};
-                        const v2f px = fma2(DY, e2z, -(DZ * e2y)), py = fma2(DZ, e2x, -(DX * e2z)), pz = fma2(DX, e2y, -(DY * e2x));
-                        const v2f det = fma2(e1z, pz, fma2(e1y, py, e1x * px));
-                        const v2f tx = OX - v0x, ty = OY - v0y, tz = OZ - v0z;
-                        const v2f un = fma2(tz, pz, fma2(ty, py, tx * px));
-                        const v2f qx = fma2(ty, e1z, -(tz * e1y)), qy = fma2(tz, e1x, -(tx * e1z)), qz = fma2(tx, e1y, -(ty * e1x));
-                        const v2f vn = fma2(DZ, qz, fma2(DY, qy, DX * qx));
-                        // det >= -dl, un >= -dl, vn >= -dl, det - un >= -2 dl, det - un - vn >= -3 dl
-                        const v2f m1 = det + dl, m2 = un + dl, m3 = vn + dl, m4 = (det - un) + 2.0f * dl, m5 = (m4 - vn) + dl;
-                        const v2f m = __builtin_elementwise_min(__builtin_elementwise_min(m1, m2),
-                                                                __builtin_elementwise_min(__builtin_elementwise_min(m3, m4), m5));
-                        pend |= ((m.x >= 0.f ? 1u : 0u) | (m.y >= 0.f ? 2u : 0u)) << k; // (a NaN fails: such a record...)
-                        // ... has NaN numerators in f64 as well (0 * inf from a degenerate ray or record) and is no hit there
+                    // RT_MESH_PAIRS pairs per step, all loaded before the first is tested: a step costs one round trip
+                    // to memory whatever it tests, and the pre-test itself is cheap
+                    for (uint32_t k = 0; k < n; k += 2u * RT_MESH_PAIRS, pr += 5 * RT_MESH_PAIRS) {
+                        float4 q[RT_MESH_PAIRS][5];
+#pragma unroll
+                        for (int pi = 0; pi < RT_MESH_PAIRS; ++pi) {
+                            const float4 *src = (k + 2u * (uint32_t)pi < n) ? pr + 5 * pi : pr; // past the end: the first again
+#pragma unroll
+                            for (int c = 0; c < 5; ++c) q[pi][c] = src[c];
+                        }
+#pragma unroll
+                        for (int pi = 0; pi < RT_MESH_PAIRS; ++pi) {
+                            const float4 q0 = q[pi][0], q1 = q[pi][1], q2 = q[pi][2], q3 = q[pi][3], q4 = q[pi][4];
+                            const v2f v0x = {q0.x, q0.y}, v0y = {q0.z, q0.w}, v0z = {q1.x, q1.y};
+                            const v2f e1x = {q1.z, q1.w}, e1y = {q2.x, q2.y}, e1z = {q2.z, q2.w};
+                            const v2f e2x = {q3.x, q3.y}, e2y = {q3.z, q3.w}, e2z = {q4.x, q4.y}, dl = {q4.z, q4.w};
+                            const v2f px = fma2(DY, e2z, -(DZ * e2y)), py = fma2(DZ, e2x, -(DX * e2z)), pz = fma2(DX, e2y, -(DY * e2x));
+                            const v2f det = fma2(e1z, pz, fma2(e1y, py, e1x * px));
+                            const v2f tx = OX - v0x, ty = OY - v0y, tz = OZ - v0z;
+                            const v2f un = fma2(tz, pz, fma2(ty, py, tx * px));
+                            const v2f qx = fma2(ty, e1z, -(tz * e1y)), qy = fma2(tz, e1x, -(tx * e1z)), qz = fma2(tx, e1y, -(ty * e1x));
+                            const v2f vn = fma2(DZ, qz, fma2(DY, qy, DX * qx));
+                            // det >= -dl, un >= -dl, vn >= -dl, det - un >= -2 dl, det - un - vn >= -3 dl
+                            const v2f m1 = det + dl, m2 = un + dl, m3 = vn + dl, m4 = (det - un) + 2.0f * dl, m5 = (m4 - vn) + dl;
+                            const v2f m = __builtin_elementwise_min(__builtin_elementwise_min(m1, m2),
+                                                                    __builtin_elementwise_min(__builtin_elementwise_min(m3, m4), m5));
+                            // (a NaN fails: such a record has NaN numerators in f64 as well and is no hit there)
+                            const uint32_t bits = (m.x >= 0.f ? 1u : 0u) | (m.y >= 0.f ? 2u : 0u);
+                            if (k + 2u * (uint32_t)pi < n) pend |= bits << (k + 2u * (uint32_t)pi);
+                        }
                     }
                     const double2 *__restrict__ rec0 = reinterpret_cast<const double2 *>(sc.cell_tris + (size_t)base * 10);
                     while (pend) {

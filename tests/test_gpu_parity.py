@@ -875,3 +875,14 @@ def test_complex_v2_hand_translation(rt):
     ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
     assert {8, 9, 10, 11, 12, 13} <= set(np.unique(rids).tolist())     # earth, tori, the three spheres, the glass ball
     _check(parity.compare(rgb, ids, ref, rids, st.strata), st, rst)
+
+
+def test_mesh_walk_stress(rt):
+    """tools/mesh_stress.py: every shipped mesh under random object transforms (non-uniform scales, rotations,
+    far translations), 40 000 rays per configuration from far away, from inside the bounds, axis-parallel - long
+    queues, so the grid walk with its f32 pre-test takes them: every ray hits the oracle's object at the oracle's
+    t (1e-9) with the oracle's normal.  A pre-test that ever rejected a hit would show here."""
+    import sys
+    sys.path.insert(0, os.path.join(parity.ROOT, "tools"))
+    import mesh_stress
+    assert mesh_stress.run(9, 40000) == 0
