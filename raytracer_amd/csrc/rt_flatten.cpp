@@ -563,7 +563,7 @@ struct Flattener {
         }
         // resolution: about `density` cells per triangle, cells as close to cubes as the bounds
         // allow, and all grids of the scene together within the LDS budget of k_mesh
-        double density = 4.0; // measured on MI355X with LinkedTorus.obj: 2..16 within 5 %, 4 best
+        double density = 2.0; // measured on MI355X with LinkedTorus.obj, k_mesh per 4K frame: 1.76 / 1.74 / 1.64 / 1.62 / 1.69 / 1.74 / 1.90 ms at 0.5 / 1 / 1.5 / 2 / 3 / 4 / 8 (with the f64 test alone 4 was best: longer lists cost more then)
         if (const char *e = std::getenv("RT_GRID_DENSITY")) density = std::atof(e); // tuning knob, not API
         uint32_t n_mesh_nodes = 0;
         for (uint32_t i = 0; i < d->n_nodes; ++i) n_mesh_nodes += d->nodes[i].kind == RT_SHAPE_MESH ? 1u : 0u;

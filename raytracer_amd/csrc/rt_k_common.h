@@ -32,6 +32,12 @@ struct HitBuf {
 #ifndef RT_MESH_PAIRS
 #define RT_MESH_PAIRS 2 // f32 record pairs k_mesh loads and pre-tests per step
 #endif
+// k_mesh's waves take their further 64-record blocks from RT_MESH_CURSORS counters (wave w from counter w mod
+// RT_MESH_CURSORS; block m of counter p is block m * RT_MESH_CURSORS + p of the queue's dynamic part): one counter
+// word sustains about 90 atomics per microsecond, which 3072 waves taking a block every few microseconds exceed
+#ifndef RT_MESH_CURSORS
+#define RT_MESH_CURSORS 16
+#endif
 #ifndef RT_MESH_WAVES
 #define RT_MESH_WAVES 3
 #endif

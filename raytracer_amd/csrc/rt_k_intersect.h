@@ -273,8 +273,10 @@ template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED>
 __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
-                                                         uint32_t *count_out, double *fb, HitBuf hit)
+                                                         uint32_t *count_out, double *fb, HitBuf hit, uint32_t *mesh_work)
 {
+    // k_mesh's block cursors start every pass at zero (this kernel precedes it on the stream)
+    if (blockIdx.x == 0 && threadIdx.x < 2 * RT_MESH_CURSORS) mesh_work[threadIdx.x * 16] = 0u;
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     __shared__ uint32_t append_lds[2 * (RT_ISECT_BLOCK / 64 + 1)];

@@ -60,8 +60,9 @@ RT_DEV void write_mesh_hit(const DevScene &sc, const RayQueue &q, const HitBuf &
 // The walk is done in grid coordinates (cells are unit cubes, the ray parameter is
 // unchanged): p_g(t) = og + dg * t.
 //
-// Waves take blocks of 64 queue entries, interleaved; with more than one block per
-// wave (large queues) a wave refills its finished lanes once `refill` of them are idle.
+// Waves take blocks of 64 queue entries: wave w starts on block w, and a wave that has used its block up takes
+// the next one nobody has taken yet (`work`, one atomic per wave and block); with more than one block per wave
+// (large queues) a wave refills its finished lanes once `refill` of them are idle.
 #ifdef RT_MESH_PROF
 __device__ unsigned long long g_pf[14]; // cycles: service, walk, test; rounds, services, lanes walking, lanes testing, waves
 #endif
@@ -121,8 +122,8 @@ RT_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c)
 
 template <bool KD, bool JOBS_LDS>
 __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q,
-                                                      const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
-                                                      uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
+                                                      const uint32_t *mesh_count, uint32_t *work, HitBuf hit,
+                                                      int32_t *primary_ids, uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
                                                       PassParams pp)
 {
     extern __shared__ double4 mesh_lds[]; // job records; then the grid tables, or the kd stacks
@@ -149,8 +150,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
 // job record `J` (an index): from LDS when it is one of the first DEV_MESH_JOBS_LDS
 #define JOB(J) (*((JOBS_LDS || (J) < (int)n_jobs_lds) ? (const DevMeshJob *)(jobs_lds + (J)) : (sc.jobs + (J))))
 
-    // every wave takes blocks of 64 queue entries, interleaved with the other waves: neighbouring
-    // rays cost about the same, so contiguous chunks would leave whole waves with the expensive ones
+    // every wave takes blocks of 64 queue entries: its own number first, then whichever comes next (neighbouring
+    // rays cost about the same, so contiguous chunks would leave whole waves with the expensive ones)
     const uint32_t count = *mesh_count;
     const uint32_t n_waves = gridDim.x * (RT_MESH_LANES / 64);
     const uint32_t wave = blockIdx.x * (RT_MESH_LANES / 64) + (threadIdx.x >> 6);
@@ -165,7 +166,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     }
     // a wave with a single block has nothing to refill from: it services its lanes twice, to load
     // the block and to store the results once every lane is done
-    if ((uint64_t)n_waves * block >= count) refill = 65u;
+    const bool single_block = (uint64_t)n_waves * block >= count;
+    if (single_block) refill = 65u;
     uint64_t cursor = (uint64_t)wave * block; // next queue entry of this wave
     uint64_t block_end = cursor + block;      // end of its current block
 
@@ -245,10 +247,23 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                     advance = true;
                 }
             }
-            cursor += (uint64_t)__popcll(empty);
-            if (cursor >= block_end) { // block used up (lanes left without a ray take from the next one)
-                cursor = block_end + (uint64_t)(n_waves - 1u) * block;
-                block_end = cursor + block;
+            if (cursor < count) {
+                cursor += (uint64_t)__popcll(empty);
+                if (cursor >= block_end) { // block used up (lanes left without a ray take from the next one)
+                    if (single_block) {
+                        cursor = count;
+                    } else {
+                        // whichever wave gets here first takes the next block: the waves stay filled until the queue is
+                        // empty, whatever their rays cost (a fixed share per wave left the waves with the cheap rays
+                        // idle through the second half of the launch)
+                        const uint32_t n_part = n_waves < RT_MESH_CURSORS ? n_waves : RT_MESH_CURSORS, part = wave % n_part;
+                        uint32_t nb = 0u;
+                        if (lane_id() == 0u) nb = atomicAdd(work + part * 16u, 1u);
+                        nb = (uint32_t)__shfl((int)nb, 0);
+                        cursor = ((uint64_t)n_waves + (uint64_t)nb * n_part + part) * block;
+                        block_end = cursor + block;
+                    }
+                }
             }
             PF_MARK(pf_b);
             if (advance) {

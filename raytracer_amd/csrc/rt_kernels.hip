@@ -72,6 +72,7 @@ struct Workspace {
     RayQueue mq;   // mesh record queue, ray part: the rays that have to visit a mesh this pass, by queue position
     HitBuf mqh;    // mesh record queue, hit part: their nearest hit so far (k_mesh merges the triangles' into it)
     uint32_t *d_counts = nullptr;   // 2 x (depth_cap + 2) + 2: live rays per depth, mesh-queue lengths per depth, k_tail's lane totals
+    uint32_t *d_work = nullptr;     // k_mesh's block cursors: 2 structures x RT_MESH_CURSORS, 64 bytes apart; zeroed by every k_intersect
     uint32_t *d_guards = nullptr;   // 8
     size_t cap = 0;                 // ray slots
     uint32_t depth_cap = 0;         // max_depth the counters are sized for
@@ -84,7 +85,7 @@ struct Workspace {
 // per-device pointer obtained at set-up (rt_scene_create), never the name.
 // RT_NOALLOC_MAX_SLOTS, RT_NOALLOC_MAX_DEPTH: rt_api.h
 #define RT_WS_BYTES_PER_SLOT 292u // carve_workspace: 33 f64 + 7 u32 arrays (two ray queues of 80 B, mesh records of 132 B)
-#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 4096u) // 95.8 MiB
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 8192u) // 95.8 MiB
 static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
 #define RT_MAX_DEVICES 64
 static void *g_noalloc_ptr[RT_MAX_DEVICES]; // device address of rt_noalloc_scratch, per device
@@ -174,6 +175,7 @@ static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Worksp
     }
     o.mqh.obj = (int32_t *)take(n, 4);
     o.d_counts = (uint32_t *)take(2 * ((size_t)max_depth + 2) + 2, 4);
+    o.d_work = (uint32_t *)take(2 * RT_MESH_CURSORS * 16, 4);
     o.d_guards = (uint32_t *)take(8, 4);
     o.cap = cap;
     o.depth_cap = max_depth;
@@ -422,10 +424,10 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     do {                                                                                                               \
         if (fused)                                                                                                     \
             hipLaunchKernelGGL((k_intersect<C, M, T, L, true>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q,   \
-                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all); \
+                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_intersect<C, M, T, L, false>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q,  \
-                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all); \
+                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work); \
     } while (0)
     // scenes whose tables do not fit LDS (scene_lds_bytes == 0) run the one variant that reads them from memory,
     // which is the most general one
@@ -455,7 +457,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
             // waves stay and refill their idle lanes from further blocks
             static const uint32_t refill = getenv("RT_MESH_REFILL") ? (uint32_t)atoi(getenv("RT_MESH_REFILL")) : 16u;
-            static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * 12u; // 4K mesh.scene: 2.09 ms with 256 x 6, 2.04-2.05 with 256 x 12, no trend beyond
+            static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * RT_MESH_WAVES; // = the waves the chip holds at once (they take blocks until the queue is empty); 4K mesh.scene: k_mesh 1.53 ms with 256 x 3, 1.58 with 256 x 6 and 256 x 12
             static const uint32_t block_env = getenv("RT_MESH_BLOCK") ? (uint32_t)atoi(getenv("RT_MESH_BLOCK")) : 0u;
             const uint64_t per_wg = RT_MESH_MIN_BLOCK * (RT_MESH_LANES / 64); // the kernel uses 4 to 64 lanes per wave
             uint64_t mb = ((uint64_t)live + per_wg - 1) / per_wg;
@@ -464,7 +466,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             const bool jobs_lds = s->dev.n_jobs <= DEV_MESH_JOBS_LDS;
 #define LAUNCH_M(KD, JL, LDS_BYTES)                                                                                    \
     hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, w.mq,        \
-                       mesh_count, w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
+                       mesh_count, w.d_work + (KD ? RT_MESH_CURSORS * 16 : 0), w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
             // one launch per structure in use: each instantiation walks its own meshes and passes the others by
             // (the record carries the nearest hit from one launch to the next)
             if (s->any_grid) {
