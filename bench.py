@@ -46,7 +46,7 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     for d in (os.path.join(ROOT, "raytracer_amd", "csrc"), os.path.join(ROOT, "include")):
         for name in sorted(os.listdir(d)):
-            if name.endswith((".h", ".hip", ".cpp")):
+            if name.endswith((".h", ".hip", ".cpp", ".inc")):
                 with open(os.path.join(d, name), "rb") as f:
                     h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()

@@ -71,10 +71,10 @@ __device__ unsigned long long g_pf[14]; // cycles: service, walk, test; rounds, 
 #define WALK_LOCATE_AXIS(OG, DG, IG, N, C, TM)                                                                         \
     do {                                                                                                               \
         double f_ = floor((OG) + (DG) * w_tc);                                                                         \
-        const double top_ = (double)((N) - 1u);                                                                        \
-        f_ = f_ > 0.0 ? f_ : 0.0; /* also sends a NaN to cell 0 */                                                     \
-        f_ = f_ > top_ ? top_ : f_;                                                                                    \
-        (C) = (int)f_;                                                                                                 \
+        f_ = f_ > 0.0 ? f_ : 0.0;         /* also sends a NaN to cell 0 */                                             \
+        f_ = f_ > 1.0e9 ? 1.0e9 : f_;     /* fits an int; the clamp to the last cell is an integer one (no double */   \
+        (C) = (int)f_;                    /* per axis to keep in registers) */                                         \
+        (C) = (C) > (int)((N) - 1u) ? (int)((N) - 1u) : (C);                                                           \
         const double edge_ = (double)((C) + ((DG) > 0.0 ? 1 : 0));                                                     \
         (TM) = (DG) != 0.0 ? (edge_ - (OG)) * (IG) : 1.0e300; /* parallel to the planes: never crosses one */          \
     } while (0)
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
                         const uint32_t n_part = n_waves < RT_MESH_CURSORS ? n_waves : RT_MESH_CURSORS, part = wave % n_part;
                         uint32_t nb = 0u;
                         if (lane_id() == 0u) nb = atomicAdd(work + part * 16u, 1u);
-                        nb = (uint32_t)__shfl((int)nb, 0);
+                        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb); // a scalar: the cursor stays the same in every lane
                         cursor = ((uint64_t)n_waves + (uint64_t)nb * n_part + part) * block;
                         block_end = cursor + block;
                     }
@@ -468,129 +468,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
             PF_MARK(pf_test);
             continue;
         }
-        // ---------------------------------------------------------------- walk to the next occupied cell
-        // "while-while": all lanes first move to their next occupied cell (LDS only), then the wave
-        // tests triangles together (the expensive part).
-        if (active) {
-            uint32_t cell = 0u;
-            bool occupied = false;
-            for (int step = 0; step < 3 * DEV_GRID_MAX_AXIS + 3; ++step) {
-                cell = ((uint32_t)cz * ny + (uint32_t)cy) * nx + (uint32_t)cx;
-                const uint32_t kd = (dist_lds[dist0 + (cell >> 3)] >> ((cell & 7u) * 4u)) & 15u;
-                if (kd == 0u) {
-                    occupied = true;
-                    break;
-                }
-                if (kd >= 2u) {
-                    // nothing within kd-1 cells of this one along any axis
-                    const double dmin = fmin(fmin(fabs(igx), fabs(igy)), fabs(igz));
-                    w_tc += ((double)kd - 1.01) * dmin;
-                    if (w_tc > t_end) {
-                        active = false;
-                        break;
-                    }
-                    WALK_LOCATE();
-                } else {
-                    bool ok;
-                    WALK_STEP(ok);
-                    if (!ok) {
-                        active = false;
-                        break;
-                    }
-                }
-            }
-            PF_MARK(pf_walk);
-#ifdef RT_MESH_PROF
-            pf_lanes_test += __popcll(__ballot(active && occupied));
-#endif
-            if (active && occupied) {
-                const uint2 gw = grid_lds[bits0 + (cell >> 5)];
-#ifdef RT_MESH_PROF
-#endif
-                const uint32_t r = cell0 + gw.y + (uint32_t)__popc(gw.x & ((1u << (cell & 31u)) - 1u));
-                uint32_t first, last;
-                if (starts_in_lds) {
-                    first = starts_lds[r];
-                    last = starts_lds[r + 1u];
-                } else {
-                    first = sc.cell_start[r];
-                    last = sc.cell_start[r + 1u];
-                }
-                // Two stages per run of records.  (1) A conservative pre-test in f32, two records per step with
-                // packed instructions (v_pk_fma_f32: 41 VALU instructions per two triangles against 154 for the
-                // reference's f64 test): a record whose numerators fail by more than its error bound cannot be a
-                // hit; the others - 1 in 20 - set a bit.  (2) The reference's own f64 test (mesh.rs:66-113) for the
-                // records whose bit is set, from the f64 copy of the run.  Runs are padded to an even length; 32
-                // records per chunk (one mask word).
-                const DevMeshJob &J = JOB(jb);
-                // the ray's entry point into this cell relative to the cell's centre: the f32 records hold v0 - centre
-                const float fox = (float)((o.x + d.x * w_tc) - (J.bmin[0] + ((double)cx + 0.5) * J.cell[0]));
-                const float foy = (float)((o.y + d.y * w_tc) - (J.bmin[1] + ((double)cy + 0.5) * J.cell[1]));
-                const float foz = (float)((o.z + d.z * w_tc) - (J.bmin[2] + ((double)cz + 0.5) * J.cell[2]));
-                const v2f OX = {fox, fox}, OY = {foy, foy}, OZ = {foz, foz};
-                const v2f DX = {(float)d.x, (float)d.x}, DY = {(float)d.y, (float)d.y}, DZ = {(float)d.z, (float)d.z};
-                for (uint32_t base = first; base < last; base += 32u) {
-                    const uint32_t n = last - base < 32u ? last - base : 32u;
-                    uint32_t pend = 0u;
-                    const float4 *__restrict__ pr = reinterpret_cast<const float4 *>(sc.cell_pairs + (size_t)(base >> 1) * 20);
-                    // RT_MESH_PAIRS pairs per step, all loaded before the first is tested: a step costs one round trip
-                    // to memory whatever it tests, and the pre-test itself is cheap
-                    for (uint32_t k = 0; k < n; k += 2u * RT_MESH_PAIRS, pr += 5 * RT_MESH_PAIRS) {
-                        float4 q[RT_MESH_PAIRS][5];
-#pragma unroll
-                        for (int pi = 0; pi < RT_MESH_PAIRS; ++pi) {
-                            const float4 *src = (k + 2u * (uint32_t)pi < n) ? pr + 5 * pi : pr; // past the end: the first again
-#pragma unroll
-                            for (int c = 0; c < 5; ++c) q[pi][c] = src[c];
-                        }
-#pragma unroll
-                        for (int pi = 0; pi < RT_MESH_PAIRS; ++pi) {
-                            const float4 q0 = q[pi][0], q1 = q[pi][1], q2 = q[pi][2], q3 = q[pi][3], q4 = q[pi][4];
-                            const v2f v0x = {q0.x, q0.y}, v0y = {q0.z, q0.w}, v0z = {q1.x, q1.y};
-                            const v2f e1x = {q1.z, q1.w}, e1y = {q2.x, q2.y}, e1z = {q2.z, q2.w};
-                            const v2f e2x = {q3.x, q3.y}, e2y = {q3.z, q3.w}, e2z = {q4.x, q4.y}, dl = {q4.z, q4.w};
-                            const v2f px = fma2(DY, e2z, -(DZ * e2y)), py = fma2(DZ, e2x, -(DX * e2z)), pz = fma2(DX, e2y, -(DY * e2x));
-                            const v2f det = fma2(e1z, pz, fma2(e1y, py, e1x * px));
-                            const v2f tx = OX - v0x, ty = OY - v0y, tz = OZ - v0z;
-                            const v2f un = fma2(tz, pz, fma2(ty, py, tx * px));
-                            const v2f qx = fma2(ty, e1z, -(tz * e1y)), qy = fma2(tz, e1x, -(tx * e1z)), qz = fma2(tx, e1y, -(ty * e1x));
-                            const v2f vn = fma2(DZ, qz, fma2(DY, qy, DX * qx));
-                            // det >= -dl, un >= -dl, vn >= -dl, det - un >= -2 dl, det - un - vn >= -3 dl
-                            const v2f m1 = det + dl, m2 = un + dl, m3 = vn + dl, m4 = (det - un) + 2.0f * dl, m5 = (m4 - vn) + dl;
-                            const v2f m = __builtin_elementwise_min(__builtin_elementwise_min(m1, m2),
-                                                                    __builtin_elementwise_min(__builtin_elementwise_min(m3, m4), m5));
-                            // (a NaN fails: such a record has NaN numerators in f64 as well and is no hit there)
-                            const uint32_t bits = (m.x >= 0.f ? 1u : 0u) | (m.y >= 0.f ? 2u : 0u);
-                            if (k + 2u * (uint32_t)pi < n) pend |= bits << (k + 2u * (uint32_t)pi);
-                        }
-                    }
-                    const double2 *__restrict__ rec0 = reinterpret_cast<const double2 *>(sc.cell_tris + (size_t)base * 10);
-                    while (pend) {
-                        const uint32_t bsel = (uint32_t)__ffs((int)pend) - 1u;
-                        pend &= pend - 1u;
-                        const double2 *__restrict__ rec = rec0 + 5 * bsel;
-                        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
-                        const d3 v0 = mk3(r0.x, r0.y, r1.x), e1 = mk3(r1.y, r2.x, r2.y), e2 = mk3(r3.x, r3.y, r4.x);
-                        const uint32_t ti = (uint32_t)__double2loint(r4.y);
-                        double t, u, v;
-                        const bool hit_ = tri_hit_v(v0, e1, e2, o, d, t, u, v);
-#ifdef RT_MESH_PROF
-                        ++pf_tests;
-                        pf_hits += hit_ ? 1u : 0u;
-#endif
-                        if (hit_ && (t < mt || (t == mt && ti < mtri))) {
-                            mt = t;
-                            mtri = ti;
-                        }
-                    }
-                }
-                // leave the cell, unless the hit found lies before its far side (slack: rounding)
-                const double t_exit = fmin(fmin(tmx, tmy), tmz);
-                bool ok = !(mt < t_exit - 1e-9 * (fabs(t_exit) + 1.0));
-                if (ok) WALK_STEP(ok);
-                if (!ok) active = false;
-            }
-        }
+#include "rt_k_mesh_grid_round.inc"
         PF_MARK(pf_test);
     }
 #ifdef RT_MESH_PROF
@@ -622,6 +500,9 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
     }
 #endif
 }
+
+#undef JOB
+#undef PF_MARK
 
 // The same merge for a short queue: one wave per ray (the reference's brute force, mesh.rs:54-64,
 // spread over 64 lanes and culled by group bounds), then a wave-wide lexicographic min over

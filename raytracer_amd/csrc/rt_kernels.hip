@@ -48,6 +48,7 @@ void set_last_error(const std::string &msg);
 #include "rt_k_common.h"
 #include "rt_k_intersect.h"
 #include "rt_k_mesh.h"
+#include "rt_k_mesh_pool.h"
 #include "rt_k_shade.h"
 
 // =====================================================================================
@@ -115,6 +116,7 @@ struct rt_scene {
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
     bool any_grid = false, any_kd = false; // (object, mesh) jobs walked through grids / through kd-trees
     uint32_t mesh_kd_lds_bytes = 0; // dynamic LDS of k_mesh<KD>: job records + stacks
+    uint32_t mesh_pool_lds_bytes = 0; // dynamic LDS of k_mesh_one (tables + the waves' stacks); 0: several jobs or no room, k_mesh walks the grids
     uint32_t host_depth_cap = 0;  // max_depth the pinned buffer and the events below are sized for
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -311,7 +313,15 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
                                     " bytes) exceed the device's LDS per workgroup (" + std::to_string(lds_limit) + ")");
             return fail(RT_ERR_UNSUPPORTED);
         }
-        RT_TRACE("k_mesh LDS: %u bytes (cell starts %s), limit %d", s->mesh_lds_bytes, s->dev.starts_in_lds ? "in LDS" : "in memory", lds_limit);
+        {
+            // k_mesh_one (a single grid job): the same tables and two stacks per wave
+            const uint32_t want = ((s->mesh_lds_bytes + 15u) & ~15u) + (RT_POOL_LANES / 64) * RT_POOL_BYTES;
+            const char *pool_env = getenv("RT_MESH_POOL"); // read per scene: "0" keeps k_mesh (measurements, tests)
+            const bool pool_off = pool_env && !strcmp(pool_env, "0");
+            s->mesh_pool_lds_bytes = (flat.jobs.size() == 1 && s->any_grid && want <= (uint32_t)lds_limit / 3u && !pool_off) ? want : 0u; // three workgroups per CU
+        }
+        RT_TRACE("k_mesh LDS: %u bytes (cell starts %s), with stacks %u, limit %d", s->mesh_lds_bytes,
+                 s->dev.starts_in_lds ? "in LDS" : "in memory", s->mesh_pool_lds_bytes, lds_limit);
     }
     if ((rc = upload(s, flat.tris, &s->dev.tris))) return fail(rc);
     if ((rc = upload(s, flat.cell_tris, &s->dev.cell_tris))) return fail(rc);
@@ -469,7 +479,16 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
                        mesh_count, w.d_work + (KD ? RT_MESH_CURSORS * 16 : 0), w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
             // one launch per structure in use: each instantiation walks its own meshes and passes the others by
             // (the record carries the nearest hit from one launch to the next)
-            if (s->any_grid) {
+            if (s->any_grid && s->mesh_pool_lds_bytes != 0u) {
+                // the scene's one job: k_mesh_one (as many workgroups as the chip holds; they take blocks until the
+                // queue is empty)
+                const uint64_t per_pool_wg = RT_MESH_MIN_BLOCK * (RT_POOL_LANES / 64);
+                uint64_t pb = ((uint64_t)live + per_pool_wg - 1) / per_pool_wg;
+                if (pb < 1) pb = 1;
+                if (pb > max_wgs) pb = max_wgs;
+                hipLaunchKernelGGL(k_mesh_one, dim3((uint32_t)pb), dim3(RT_POOL_LANES), s->mesh_pool_lds_bytes, st, s->dev, w.mq,
+                                   mesh_count, w.d_work, w.mqh, ids, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+            } else if (s->any_grid) {
                 if (jobs_lds)
                     LAUNCH_M(false, true, s->mesh_lds_bytes);
                 else

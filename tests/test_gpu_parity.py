@@ -886,3 +886,22 @@ def test_mesh_walk_stress(rt):
     sys.path.insert(0, os.path.join(parity.ROOT, "tools"))
     import mesh_stress
     assert mesh_stress.run(9, 40000) == 0
+
+
+def test_mesh_kernels_agree(rt, monkeypatch):
+    """k_mesh_one (one grid job in the scene: PREPARE / FINISH batches around the walk) and k_mesh (RT_MESH_POOL=0)
+    write the same records: images, ids and ray counts bit for bit, on mesh.scene (long and short queues: 640x360
+    goes from the grid walk through the wave-per-ray kernel to the tail) and on traced rays."""
+    o = rt.Options(width=640, height=360, samples=4, seed=9)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    ro, rd = _random_rays(120000, 5, np.array([0.0, 1.0, 0.0]), 2.5)
+    out = []
+    for pool in ("1", "0"):
+        monkeypatch.setenv("RT_MESH_POOL", pool)
+        dev = rt.DeviceScene(sc)
+        rgb, ids, st = dev.render(o)
+        got, _ = dev.trace_rays(ro, rd, seed=4)
+        out.append((rgb, ids, st.rays, got))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    for k in ("object", "t", "n", "uv"):
+        assert np.array_equal(out[0][3][k], out[1][3][k]), k
