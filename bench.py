@@ -298,7 +298,13 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("sources_sha256") == kernel_sources_sha():
-                    traffic = tj.get("k_mesh_hbm_bytes_per_launch")
+                    # the grid walk is k_mesh_one in a scene with one mesh job (mesh.scene), k_mesh otherwise: the
+                    # profile of this command names the one that ran
+                    for name in ("k_mesh_one", "k_mesh"):
+                        if tj.get(name + "_hbm_bytes_per_launch") is not None:
+                            traffic = tj.get(name + "_hbm_bytes_per_launch")
+                            kernels[0]["kernel"] = name
+                            break
                     traffic_note = "profiles/traffic.json, measured on these kernel sources"
                 else:
                     traffic_note = "profiles/traffic.json was measured on other kernel sources: withheld"
@@ -311,6 +317,7 @@ def main():
                         "launch shares the GPU with the other frames' kernels while it runs; `one_frame_at_a_time` holds the "
                         "same figure with the GPU to itself.  k_mesh is bound by VALU issue at low lane occupancy, not by HBM "
                         "(DESIGN.md): its HBM fraction is low by construction" % F)
+        roof["kernel_note"] = "k_mesh = the grid-walk stage; in a scene with one mesh job the kernel launched is k_mesh_one (rt_k_mesh_pool.h)"
         ms_mesh_alone = sum(st.ms_mesh for st in alone)
         mesh_rays_alone = sum(st.mesh_rays for st in alone)
         n_mesh_alone = sum(st.n_mesh_launches for st in alone)

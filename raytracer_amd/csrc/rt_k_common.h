@@ -35,6 +35,12 @@ struct HitBuf {
 // k_mesh's waves take their further 64-record blocks from RT_MESH_CURSORS counters (wave w from counter w mod
 // RT_MESH_CURSORS; block m of counter p is block m * RT_MESH_CURSORS + p of the queue's dynamic part): one counter
 // word sustains about 90 atomics per microsecond, which 3072 waves taking a block every few microseconds exceed
+// cells a lane crosses per round before the wave turns to the triangle lists (a lane still in empty cells
+// then goes on in the next round).  The same limit on the records tested per round (a lane with a long run going
+// on in the next round) gained nothing: 1.29 / 1.30 / 1.42 / 1.71 ms at 32 / 16 / 8 / 4 records.
+#ifndef RT_WALK_STEPS
+#define RT_WALK_STEPS 4 // 4K mesh.scene, k_mesh_one per frame: 1.69 / 1.44 / 1.27 / 1.26 / 1.28 / 1.36 ms at 1 / 2 / 3 / 4 / 6 / 12, 1.39 without a limit
+#endif
 #ifndef RT_MESH_CURSORS
 #define RT_MESH_CURSORS 16
 #endif
