@@ -3,14 +3,14 @@
 cd $GRAFT_REPO_ROOT
 : > gpurun_out/configs.jsonl
 run() { timeout -k 10 280 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grep '"metric"' >> gpurun_out/configs.jsonl || echo "FAILED: $*"; }
-run --scene cornell_box --width 1920 --height 1080 --steps 5 --warmup 1
-run --scene mesh_monkey --width 3840 --height 2160 --steps 5 --warmup 1
-run --scene torus --width 3840 --height 2160 --steps 5 --warmup 1
-run --scene csg --width 3840 --height 2160 --steps 5 --warmup 1
-run --scene three-spheres --width 3840 --height 2160 --steps 5 --warmup 1
-run --scene room --width 3840 --height 2160 --steps 3 --warmup 1
-run --scene complex_v2 --width 3840 --height 2160 --steps 3 --warmup 1
-run --scene fog_light --width 7680 --height 4320 --samples 16 --steps 1 --warmup 1
+run --scene cornell_box --width 1920 --height 1080 --steps 16 --warmup 2
+run --scene mesh_monkey --width 3840 --height 2160 --steps 16 --warmup 2
+run --scene torus --width 3840 --height 2160 --steps 16 --warmup 2
+run --scene csg --width 3840 --height 2160 --steps 16 --warmup 2
+run --scene three-spheres --width 3840 --height 2160 --steps 16 --warmup 2
+run --scene room --width 3840 --height 2160 --steps 8 --warmup 1
+run --scene complex_v2 --width 3840 --height 2160 --steps 8 --warmup 1
+run --scene fog_light --width 7680 --height 4320 --samples 16 --steps 4 --warmup 1
 python - <<'PY'
 import json
 for l in open("gpurun_out/configs.jsonl"):
