@@ -114,7 +114,7 @@ __device__ unsigned long long g_pf[14]; // cycles: service, walk, test; rounds, 
 // entries: node and the far bound of its cell as an f32 rounded up; cells come in ray order, so
 // the near bound of a popped cell is the far bound of the leaf just finished), leaf triangles as
 // contiguous 80-byte records.  Everything around the walk - queue blocks, refill, job records,
-// the merge - is shared.  rt_scene_create picks the structure per scene.
+// the merge - is shared.  The flattener picks the structure per mesh (DevMeshJob::use_kd).
 // JOBS_LDS: every job record is in LDS (at most DEV_MESH_JOBS_LDS of them).  A compile-time fact on purpose:
 // a run-time choice between the LDS copy and memory makes each field access a flat load.
 typedef float v2f __attribute__((ext_vector_type(2)));

@@ -15,7 +15,7 @@
 //
 //   PREPARE  up to 64 new records: ray, recorded hit, frame map, box tests -> `ready` stack
 //            (record number, ray in object space, entry and exit parameter, walk steps per cell: 92 bytes)
-//   pop      an idle lane takes the top of `ready` (LDS reads, three divisions for the grid entry) and walks
+//   pop      an idle lane takes the top of `ready` (LDS reads and the grid cell of the entry point) and walks
 //   round    rt_k_mesh_grid_round.inc, as in k_mesh
 //   walk end a ray that met a triangle pushes (record number, t, triangle) onto the `done` stack: 16 bytes
 //   FINISH   up to 64 `done` entries: Intersection::to_world's t, the comparison with the recorded hit, normal, uv,

@@ -464,8 +464,8 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             if (blocks < 1) blocks = 1;
             hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), dim3(RT_BLOCK), 0, st, s->dev, w.mq, mesh_count, w.mqh, ids, pp);
         } else {
-            // one 64-ray block per wave while the waves fit the chip a few times over; beyond that the
-            // waves stay and refill their idle lanes from further blocks
+            // as many waves as the chip holds: wave w starts on block w of 64 records and takes further blocks from
+            // the cursors (d_work) until the queue is empty; short queues: fewer lanes per wave (block < 64)
             static const uint32_t refill = getenv("RT_MESH_REFILL") ? (uint32_t)atoi(getenv("RT_MESH_REFILL")) : 16u;
             static const uint32_t max_wgs = getenv("RT_MESH_WGS") ? (uint32_t)atoi(getenv("RT_MESH_WGS")) : 256u * RT_MESH_WAVES; // = the waves the chip holds at once (they take blocks until the queue is empty); 4K mesh.scene: k_mesh 1.53 ms with 256 x 3, 1.58 with 256 x 6 and 256 x 12
             static const uint32_t block_env = getenv("RT_MESH_BLOCK") ? (uint32_t)atoi(getenv("RT_MESH_BLOCK")) : 0u;
