@@ -45,6 +45,7 @@ BYTES_PER_RAY_SHADE = 132 + 80      # mesh record (ray + hit) read, scattered ra
 BYTES_PER_RAY_FRAME = 2 * 80 + 2 * 52
 BYTES_PER_PIXEL_SAMPLE = 24
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 78.6              # FP64 vector peak
 
 
 def kernel_sources_sha():
@@ -299,6 +300,7 @@ def main():
         # The file records the kernel sources it was measured on; after any change to them the figure is
         # withheld (null) rather than quoted stale.
         traffic, traffic_note = None, "no PMC measurement committed"
+        tj = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -317,6 +319,25 @@ def main():
                     traffic_note = "profiles/traffic.json was measured on other kernel sources: withheld"
             except Exception:
                 traffic = None
+        # The other side of the roofline (FP64 VALU, 78.6 TFLOP/s vector peak = 1024 SIMDs x one 64-lane
+        # instruction per 4 cycles): wave-level VALU instructions per frame from the SQ pass of the same profile, over
+        # this run's frame time.  Instructions, not flops: a bound from above on both counts.
+        valu = None
+        try:
+            if tj.get("sources_sha256") == kernel_sources_sha():
+                per = {k[:-len("_valu_wave_instructions_per_frame")]: v for k, v in tj.items() if k.endswith("_valu_wave_instructions_per_frame")}
+                if per and args.scene == SCENE and args.width == WIDTH and args.height == HEIGHT and args.samples == SAMPLES:
+                    insts = sum(per.values()) / max(1, world)   # per GPU: the frame's rays are split over the ranks
+                    lanes = sum(v * tj.get(k + "_valu_lanes_per_instruction", 0.0) for k, v in per.items()) / max(1, world)
+                    peak_issue = VALU_PEAK_TFLOPS * 1e12 / 128.0  # wave instructions per second (an FMA on 64 lanes = 128 flop)
+                    valu = {"bound": "fp64 valu issue", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "wave_instructions_per_frame": per, "issue_slots_used": insts / (dt / args.steps) / peak_issue,
+                            "tflops_if_every_lane_instruction_were_an_fma": lanes * 2.0 / (dt / args.steps) / 1e12,
+                            "frac": lanes * 2.0 / (dt / args.steps) / 1e12 / VALU_PEAK_TFLOPS,
+                            "lanes_per_instruction": {k: tj.get(k + "_valu_lanes_per_instruction") for k in per},
+                            "source": "profiles/traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the same command, one frame at a time)"}
+        except Exception:
+            valu = None
         roof = dict(kernels[0])
         roof["traffic"] = traffic
         roof["traffic_source"] = traffic_note
@@ -340,6 +361,7 @@ def main():
                        "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps,
                        "frames_in_flight": F},
             "roofline": roof,
+            "roofline_valu": valu,
             "kernels": kernels[1:],
             # the same K steps again without the per-kernel events of the timed region (what rt_render costs a caller
             # that does not ask for stage times)

@@ -12,5 +12,5 @@ tools/pmc.sh $tag "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
   "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA" || exit 1
 python tools/pmc_sum.py gpurun_out/pmc_${tag}_3.csv gpurun_out/pmc_${tag}_4.csv > gpurun_out/${tag}_pmc_sq_summary.txt
-python tools/traffic.py gpurun_out/pmc_${tag}_1.csv gpurun_out/pmc_${tag}_2.csv gpurun_out/${tag}_traffic.json > /dev/null
+python tools/traffic.py gpurun_out/pmc_${tag}_1.csv gpurun_out/pmc_${tag}_2.csv gpurun_out/${tag}_traffic.json gpurun_out/pmc_${tag}_3.csv > /dev/null
 echo done
