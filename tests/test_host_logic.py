@@ -414,3 +414,64 @@ def test_greyscale_jpeg_with_sampling_factors(rt, tmp_path):
     assert d.n_images == 1 and d.images[0].width == 70 and d.images[0].height == 45
     got = np.ctypeslib.as_array(d.image_data, shape=(d.n_image_bytes,))[:70 * 45 * 3].reshape(45, 70, 3).astype(int)
     assert np.abs(got - want).max() <= 3 and np.abs(got - want).mean() < 0.5
+
+
+# ---------------------------------------------------------------- the f32 pre-test of the mesh kernels, on the host
+def _pretest_probe():
+    """tests/helpers/pretest_probe.cpp: the product's flattener and f64 triangle test as host code, around a host copy
+    of the pre-test's f32 arithmetic (built here with g++, -ffp-contract=off)."""
+    import subprocess
+    src = os.path.join(parity.ROOT, "tests", "helpers", "pretest_probe.cpp")
+    out = os.path.join(parity.ROOT, "tests", "helpers", "_pretest_probe.so")
+    csrc = os.path.join(parity.ROOT, "raytracer_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("rt_flatten.cpp", "rt_flatten.h", "rt_device.h", "rt_dev_shapes.h", "rt_dev_math.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
+                               "-I" + os.path.join(parity.ROOT, "tools", "host_shim"), "-I" + csrc,
+                               "-I" + os.path.join(parity.ROOT, "include"), src, os.path.join(csrc, "rt_flatten.cpp"), "-o", out])
+    lib = C.CDLL(out)
+    lib.probe_pretest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.probe_pretest.restype = C.c_int
+    return lib
+
+
+def test_f32_pretest_never_rejects_a_hit(rt, tmp_path):
+    """Stage 1 of the mesh kernels' triangle test (rt_k_mesh_grid_round.inc) may reject a triangle only when the
+    reference's f64 test (stage 2, tri_hit_v) would reject it too.  The probe runs both on the host, from the
+    flattener's own records, for random rays through every occupied grid cell: the shipped meshes, and LinkedTorus.obj
+    with its vertices scaled by 1e-3 and 1e3 and moved 1e4 away from the origin (the records are relative to the cell
+    centre and the error bound to the cell's size, so none of these may matter) - origins in the cell, 10 and 1000
+    units back, a quarter of the rays entering through a face, a quarter aimed at an edge or a corner of one of the
+    cell's triangles (where the f64 test decides by the last bit: with the error bound set to zero the probe counts
+    a thousand missed hits on LinkedTorus.obj), some axis-parallel.  No hit is missed in up to 2 M
+    triangle tests per mesh, and the pre-test passes little more than the hits (it is worth having)."""
+    lib = _pretest_probe()
+    o = rt.Options(width=8, height=8)
+    src = open(os.path.join(parity.ASSETS, "LinkedTorus.obj")).read().splitlines()
+
+    def variant(name, scale, shift):
+        with open(tmp_path / name, "w") as f:
+            for line in src:
+                if line.startswith("v "):
+                    x, y, z = [float(v) for v in line.split()[1:4]]
+                    line = "v %.17g %.17g %.17g" % (x * scale[0] + shift[0], y * scale[1] + shift[1], z * scale[2] + shift[2])
+                f.write(line + "\n")
+
+    variant("small.obj", (1e-3, 2e-3, 1.5e-3), (0.0, 0.0, 0.0))
+    variant("large.obj", (1e3, 3e2, 2e3), (0.0, 0.0, 0.0))
+    variant("far.obj", (1.0, 1.0, 1.0), (1e4, -2e4, 5e3))
+    variant("flat.obj", (1.0, 1e-4, 1.0), (3.0, 4.0, 5.0))
+    cases = [(parity.ASSETS, "LinkedTorus.obj"), (parity.ASSETS, "Monkey.obj"), (parity.ASSETS, "two_parts.obj"),
+             (str(tmp_path), "small.obj"), (str(tmp_path), "large.obj"), (str(tmp_path), "far.obj"), (str(tmp_path), "flat.obj")]
+    for k, (base, mesh) in enumerate(cases):
+        text = ('camera { origin <0, 0, 9> look_at <0, 0, 0> }\n'
+                'object "m" { mesh { file "%s" transform { rotate_y 30 translate <0, 1, 0> } } '
+                'material { lambertian texture { solid color white } } }\n' % mesh)
+        sc = rt.parse(o, text, base)
+        out = (C.c_uint64 * 8)()
+        assert lib.probe_pretest(C.cast(sc.desc, C.c_void_p), 48, 100 + k, out) == 0
+        cells, tested, hits, passed, missed, jobs, aimed, _ = [int(v) for v in out]
+        print(mesh, list(out))
+        assert jobs >= 1 and cells > 20 and tested > (100000 if cells > 200 else 5000) and hits > tested // 200, (mesh, list(out))
+        assert missed == 0 and aimed > cells // 4, (mesh, list(out))
+        assert passed < 2.0 * hits, (mesh, list(out))
