@@ -473,5 +473,5 @@ def test_f32_pretest_never_rejects_a_hit(rt, tmp_path):
         cells, tested, hits, passed, missed, jobs, aimed, _ = [int(v) for v in out]
         print(mesh, list(out))
         assert jobs >= 1 and cells > 20 and tested > (100000 if cells > 200 else 5000) and hits > tested // 200, (mesh, list(out))
-        assert missed == 0 and aimed > cells // 4, (mesh, list(out))
+        assert missed == 0 and aimed >= 20, (mesh, list(out))
         assert passed < 2.0 * hits, (mesh, list(out))
