@@ -40,8 +40,10 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SAMPLES = 3840, 2160, 1
 SCENE = "mesh"
 BYTES_PER_RAY_INTERSECT = 80 + 80   # ray record read; scattered ray written (or a 132 B mesh record, or 24 B of frame buffer)
-BYTES_PER_RAY_MESH = 48 + 12 + 52   # mesh record by position: origin + direction, recorded hit (t, object) read; hit record written
+BYTES_PER_RAY_MESH = 48 + 12 + 52   # k_mesh: mesh record by position (origin + direction, recorded hit t + object) read; hit record written
+BYTES_PER_RAY_MESH_ONE = 48 + 12 + 12  # k_mesh_one: the same read; t and triangle written (k_shade merges them into the hit)
 BYTES_PER_RAY_SHADE = 132 + 80      # mesh record (ray + hit) read, scattered ray written (or 24 B of frame buffer updated)
+BYTES_PER_RAY_SHADE_ONE = 132 + 12 + 80  # after k_mesh_one: its t and triangle read as well
 BYTES_PER_RAY_FRAME = 2 * 80 + 2 * 52
 BYTES_PER_PIXEL_SAMPLE = 24
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -247,7 +249,8 @@ def main():
                ms_shade=sum(st.ms_shade for st in stats), ms_tail=sum(st.ms_tail for st in stats),
                ms_raygen=sum(st.ms_raygen for st in stats), n_int=sum(st.n_intersect_launches for st in stats),
                n_mesh=sum(st.n_mesh_launches for st in stats), int_rays=sum(st.intersect_rays for st in stats),
-               mesh_rays=sum(st.mesh_rays for st in stats), mesh_records=sum(st.mesh_records for st in stats))
+               mesh_rays=sum(st.mesh_rays for st in stats), mesh_records=sum(st.mesh_records for st in stats),
+               mesh_one_rays=sum(st.mesh_one_rays for st in stats))
     if args.timed_only:
         dt_plain = dt
     else:
@@ -293,9 +296,12 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch":
                     rays_k / launches if launches else None, "avg_launch_ms": ms / launches if launches else None,
                     "launches": launches, "ms_per_step": ms / args.steps}
-        kernels = [line("k_mesh", acc["mesh_rays"], BYTES_PER_RAY_MESH, acc["ms_mesh"], acc["n_mesh"]),
+        # which mesh kernel walked the grids (rt_stats.mesh_one_rays): k_mesh_one writes 12 bytes per ray, k_mesh 52
+        one = acc["mesh_rays"] > 0 and acc["mesh_one_rays"] == acc["mesh_rays"]
+        mesh_kernel, mesh_bytes = ("k_mesh_one", BYTES_PER_RAY_MESH_ONE) if one else ("k_mesh", BYTES_PER_RAY_MESH)
+        kernels = [line(mesh_kernel, acc["mesh_rays"], mesh_bytes, acc["ms_mesh"], acc["n_mesh"]),
                    line("k_intersect", acc["int_rays"], BYTES_PER_RAY_INTERSECT, acc["ms_int"], acc["n_int"]),
-                   line("k_shade", acc["mesh_records"], BYTES_PER_RAY_SHADE, acc["ms_shade"], acc["n_int"])]
+                   line("k_shade", acc["mesh_records"], BYTES_PER_RAY_SHADE_ONE if one else BYTES_PER_RAY_SHADE, acc["ms_shade"], acc["n_int"])]
         # HBM bytes per k_mesh launch from the PMC passes over this same command (tools/pmc.sh, tools/traffic.py).
         # The file records the kernel sources it was measured on; after any change to them the figure is
         # withheld (null) rather than quoted stale.
@@ -307,13 +313,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("sources_sha256") == kernel_sources_sha():
-                    # the grid walk is k_mesh_one in a scene with one mesh job (mesh.scene), k_mesh otherwise: the
-                    # profile of this command names the one that ran
-                    for name in ("k_mesh_one", "k_mesh"):
-                        if tj.get(name + "_hbm_bytes_per_launch") is not None:
-                            traffic = tj.get(name + "_hbm_bytes_per_launch")
-                            kernels[0]["kernel"] = name
-                            break
+                    traffic = tj.get(mesh_kernel + "_hbm_bytes_per_launch")
                     traffic_note = "profiles/traffic.json, measured on these kernel sources"
                 else:
                     traffic_note = "profiles/traffic.json was measured on other kernel sources: withheld"
@@ -345,7 +345,7 @@ def main():
                         "launch shares the GPU with the other frames' kernels while it runs; `one_frame_at_a_time` holds the "
                         "same figure with the GPU to itself.  k_mesh is bound by VALU issue at low lane occupancy, not by HBM "
                         "(DESIGN.md): its HBM fraction is low by construction" % F)
-        roof["kernel_note"] = "k_mesh = the grid-walk stage; in a scene with one mesh job the kernel launched is k_mesh_one (rt_k_mesh_pool.h)"
+        roof["kernel_note"] = "the mesh stage: k_mesh_one in a scene with one mesh job (rt_k_mesh_pool.h), k_mesh otherwise; rt_stats.mesh_one_rays says which"
         ms_mesh_alone = sum(st.ms_mesh for st in alone)
         mesh_rays_alone = sum(st.mesh_rays for st in alone)
         n_mesh_alone = sum(st.n_mesh_launches for st in alone)
@@ -368,7 +368,7 @@ def main():
             "uninstrumented": {"value": rays_total / dt_plain / 1e6, "unit": "Mrays/s", "ms_per_step": dt_plain / args.steps * 1e3},
             # the same K steps one frame after the other: the latency of a frame, and k_mesh with the GPU to itself
             "one_frame_at_a_time": {"ms_per_step": dt_alone / args.steps * 1e3, "value": rays_alone / dt_alone / 1e6, "unit": "Mrays/s",
-                                    "k_mesh": line("k_mesh", mesh_rays_alone, BYTES_PER_RAY_MESH, ms_mesh_alone, n_mesh_alone)},
+                                    "k_mesh": line(mesh_kernel, mesh_rays_alone, mesh_bytes, ms_mesh_alone, n_mesh_alone)},
             "stage_ms_per_step": {"raygen": acc["ms_raygen"] / args.steps, "intersect": acc["ms_int"] / args.steps,
                                   "mesh": acc["ms_mesh"] / args.steps, "shade": acc["ms_shade"] / args.steps,
                                   "tail": acc["ms_tail"] / args.steps},

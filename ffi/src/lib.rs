@@ -190,6 +190,7 @@ pub struct rt_stats {
     pub mesh_rays: u64,
     pub intersect_rays: u64,
     pub mesh_records: u64,
+    pub mesh_one_rays: u64,
 }
 
 #[repr(C)]

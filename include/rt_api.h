@@ -204,6 +204,8 @@ typedef struct rt_stats {
     uint64_t mesh_rays;            /* rays those k_mesh launches walked         */
     uint64_t intersect_rays;       /* rays those k_intersect launches took      */
     uint64_t mesh_records;         /* rays that went through the mesh record queue (k_mesh or k_mesh_brute, then k_shade) */
+    uint64_t mesh_one_rays;        /* of mesh_rays: walked by k_mesh_one (scenes with one mesh job), which leaves the merge
+                                    * of its triangle into the record's hit to k_shade */
 } rt_stats;
 
 /* Nearest-hit record, one per ray: RayHit (system.rs:154-171). */
@@ -287,7 +289,7 @@ int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_option
 /* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same outputs (bit for
  * bit), but the wavefront state (ray queues, hit records, mesh queue, counters) lives in a static device
- * array of the library (95.8 MiB per GPU the library runs on, held until the process ends) instead of a
+ * array of the library (99.8 MiB per GPU the library runs on, held until the process ends) instead of a
  * workspace the scene allocates and grows, and the call makes no hipMalloc / hipFree / hipHostMalloc /
  * hipEventCreate: everything else it needs was set up by rt_scene_create.  Limits: a shard of at most
  * RT_NOALLOC_MAX_SLOTS ray slots (rt_shard_pixels(opts); 640 x 480 fits) and max_depth <=

@@ -85,7 +85,8 @@ class rt_stats(C.Structure):
                 ("ms_device", C.c_double), ("ms_raygen", C.c_double), ("ms_intersect", C.c_double),
                 ("ms_shade", C.c_double), ("ms_mesh", C.c_double), ("ms_tail", C.c_double),
                 ("n_intersect_launches", C.c_uint32), ("n_mesh_launches", C.c_uint32),
-                ("mesh_rays", C.c_uint64), ("intersect_rays", C.c_uint64), ("mesh_records", C.c_uint64)]
+                ("mesh_rays", C.c_uint64), ("intersect_rays", C.c_uint64), ("mesh_records", C.c_uint64),
+                ("mesh_one_rays", C.c_uint64)]
 
 
 class rt_hit(C.Structure):

@@ -273,7 +273,7 @@ template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED>
 __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
-                                                         uint32_t *count_out, double *fb, HitBuf hit, uint32_t *mesh_work)
+                                                         uint32_t *count_out, double *fb, HitBuf hit, uint32_t *mesh_work, uint32_t *mesh_res_tri)
 {
     // k_mesh's block cursors start every pass at zero (this kernel precedes it on the stream)
     if (blockIdx.x == 0 && threadIdx.x < 2 * RT_MESH_CURSORS) mesh_work[threadIdx.x * 16] = 0u;
@@ -349,6 +349,7 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
             mqh.uv[0][at_m] = h.u;
             mqh.uv[1][at_m] = h.v;
             mqh.obj[at_m] = h.obj;
+            if (mesh_res_tri) mesh_res_tri[at_m] = 0xFFFFFFFFu; // k_mesh_one's result for this record: none yet
         }
         if (FUSED && alive) {
             qout.o[0][at_q] = o.x;
@@ -367,19 +368,4 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
     for (int k = 0; k < 5; ++k)
         if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
     if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
-}
-
-// rt_trace_rays: the merged hit of mesh record j back to its ray's slot in the per-ray hit buffer
-__global__ void k_copy_mesh_hits(RayQueue mq, HitBuf mqh, const uint32_t *mesh_count, HitBuf hit)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= *mesh_count) return;
-    const uint32_t i = mq.slot[j];
-    hit.t[i] = mqh.t[j];
-    hit.n[0][i] = mqh.n[0][j];
-    hit.n[1][i] = mqh.n[1][j];
-    hit.n[2][i] = mqh.n[2][j];
-    hit.uv[0][i] = mqh.uv[0][j];
-    hit.uv[1][i] = mqh.uv[1][j];
-    hit.obj[i] = mqh.obj[j];
 }

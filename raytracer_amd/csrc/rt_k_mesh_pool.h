@@ -10,26 +10,24 @@
 // that happen to be idle (it waits for 16), each time with two or three dependent trips to memory, and with the
 // walk state of the other lanes held in registers meanwhile.  With one job in the scene (one mesh object made of
 // one mesh: every mesh scene the reference ships) there is no job loop and no merge over objects to carry along,
-// the job's constants are the same for every lane (scalar registers), and the two halves become batches of their
-// own, run by all 64 lanes on up to 64 records, with two LDS stacks per wave in between:
+// the job's constants are the same for every lane (scalar registers), and the two halves leave the walk:
 //
-//   PREPARE  up to 64 new records: ray, recorded hit, frame map, box tests -> `ready` stack
-//            (record number, ray in object space, entry and exit parameter, walk steps per cell: 92 bytes)
+//   PREPARE  a batch of its own, all 64 lanes on up to 64 new records: ray, recorded hit, frame map, box tests ->
+//            the wave's `ready` stack in LDS (record number, ray in object space, entry and exit parameter, walk
+//            steps per cell: 92 bytes)
 //   pop      an idle lane takes the top of `ready` (LDS reads and the grid cell of the entry point) and walks
 //   round    rt_k_mesh_grid_round.inc, as in k_mesh
-//   walk end a ray that met a triangle pushes (record number, t, triangle) onto the `done` stack: 16 bytes
-//   FINISH   up to 64 `done` entries: Intersection::to_world's t, the comparison with the recorded hit, normal, uv,
-//            the hit record
+//   walk end a ray that met a triangle stores (t in object space, triangle) at its record's place: 12 bytes
+//   finish   in k_shade, which holds the record's ray and hit in registers anyway (mesh_one_finish, rt_k_shade.h):
+//            Intersection::to_world's t, the comparison with the recorded hit, normal, uv
 //
-// Same arithmetic per ray as k_mesh (the same expressions on the same inputs), so the two kernels write identical
-// records (test_mesh_kernels_agree); scenes with several jobs, with a kd-tree, or whose grid tables leave no room
+// Same arithmetic per ray as k_mesh (the same expressions on the same inputs), so the two kernels lead to identical
+// images (test_mesh_kernels_agree); scenes with several jobs, with a kd-tree, or whose grid tables leave no room
 // for the stacks run k_mesh.
 #define RT_POOL_LANES 256
 #define RT_POOL_READY 80u // entries; a PREPARE batch is min(64, RT_POOL_READY - entries in the stack) records
-#define RT_POOL_DONE 96u  // entries; FINISH runs once more than RT_POOL_DONE - 64 are waiting
 #define RT_POOL_READY_BYTES (RT_POOL_READY * 92u)
-#define RT_POOL_DONE_BYTES (RT_POOL_DONE * 16u)
-#define RT_POOL_BYTES (RT_POOL_READY_BYTES + RT_POOL_DONE_BYTES) // per wave
+#define RT_POOL_BYTES RT_POOL_READY_BYTES // per wave
 #ifndef RT_POOL_POP_MIN
 #define RT_POOL_POP_MIN 8u // idle lanes before the wave stops to refill them
 #endif
@@ -45,7 +43,7 @@ RT_DEV double uniform_f64(double v)
 }
 
 __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene sc, RayQueue q, const uint32_t *mesh_count,
-                                                                        uint32_t *work, HitBuf hit, int32_t *primary_ids,
+                                                                        uint32_t *work, HitBuf hit, double *res_t, uint32_t *res_tri,
                                                                         uint32_t block_arg, uint32_t resident_waves, PassParams pp)
 {
     extern __shared__ double4 mesh_lds[]; // the job record, grid tables, then the waves' stacks
@@ -73,8 +71,6 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
                           (size_t)(threadIdx.x >> 6) * RT_POOL_BYTES;
     double *r_f = reinterpret_cast<double *>(pool);                        // o[3], d[3], t0, t1, ig[3]: 11 x RT_POOL_READY
     uint32_t *r_u = reinterpret_cast<uint32_t *>(r_f + 11 * RT_POOL_READY); // record number
-    double *d_f = reinterpret_cast<double *>(pool + RT_POOL_READY_BYTES);  // t
-    uint32_t *d_u = reinterpret_cast<uint32_t *>(d_f + RT_POOL_DONE);      // record number, triangle
 
     const uint32_t count = *mesh_count;
     const uint32_t n_waves = gridDim.x * (RT_POOL_LANES / 64);
@@ -91,7 +87,7 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
     uint64_t cursor = (uint64_t)wave * block; // next queue entry of this wave
     uint64_t block_end = cursor + block;      // end of its current block
     if (cursor > count) cursor = count;
-    uint32_t nr = 0u, nd = 0u; // entries in the stacks (the same in every lane)
+    uint32_t nr = 0u; // entries in the stack (the same in every lane)
 
     // the job's constants: the same in every lane
     const uint32_t nx = uniform_u32(JOB(0).n[0]), ny = uniform_u32(JOB(0).n[1]), nz = uniform_u32(JOB(0).n[2]);
@@ -121,7 +117,7 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
     uint32_t mtri = 0xFFFFFFFFu;
     bool walked = false; // a walk has ended in this lane and its result has not been pushed yet
 #ifdef RT_MESH_PROF
-    // reported in k_mesh's format: "reload+merge" = push, "fetch" = PREPARE, "advance" = pop, "write" = FINISH;
+    // reported in k_mesh's format: "reload+merge" = walk end, "fetch" = PREPARE, "advance" = pop, "write" = -;
     // services = PREPARE batches
     long long pf_t = clock64(), pf_walk = 0, pf_test = 0, pf_a = 0, pf_b = 0, pf_c = 0, pf_d = 0;
     unsigned long long pf_rounds = 0, pf_services = 0, pf_lanes_walk = 0, pf_lanes_test = 0, pf_tests = 0, pf_hits = 0;
@@ -131,19 +127,13 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
 #endif
 
     for (;;) {
-        // ---------------------------------------------------------------- walk end: nearest triangle -> `done`
-        {
-            const bool through = walked && !active;
-            const bool push = through && mtri != 0xFFFFFFFFu;
-            const uint64_t pushing = __ballot(push);
-            if (push) {
-                const uint32_t e = nd + (uint32_t)__popcll(pushing & lane_lt);
-                d_f[e] = mt;
-                d_u[e] = ri;
-                d_u[RT_POOL_DONE + e] = mtri;
+        // ---------------------------------------------------------------- walk end: the nearest triangle, for k_shade
+        if (walked && !active) {
+            if (mtri != 0xFFFFFFFFu) {
+                res_t[ri] = mt; // object-space t; k_shade (mesh_one_finish) merges it with the recorded hit
+                res_tri[ri] = mtri;
             }
-            nd += (uint32_t)__popcll(pushing);
-            if (through) walked = false;
+            walked = false;
         }
         const uint64_t idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -244,49 +234,7 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
             PF_MARK(pf_c);
         }
 
-        // ---------------------------------------------------------------- FINISH: merge, normal, uv, hit record
         const bool nothing_left = __ballot(active) == 0ull && nr == 0u && cursor >= count;
-        while (nd > RT_POOL_DONE - 64u || (nothing_left && nd > 0u)) {
-            const uint32_t batch = nd < 64u ? nd : 64u;
-            if (lane_id() < batch) {
-                const uint32_t e = nd - 1u - lane_id();
-                const double obj_t = d_f[e];
-                const uint32_t fri = d_u[e], tri = d_u[RT_POOL_DONE + e];
-                d3 wo, wd;
-                uint32_t px_;
-                (void)fetch_ray(sc, q, pp, fri, wo, wd, px_);
-                const int rec_obj = hit.obj[fri];
-                const double recorded_t = hit.t[fri];
-                const DevMeshJob &B = JOB(0);
-                d3 bo = wo, bd = wd;
-                double tw = obj_t; // Intersection::to_world's t (system.rs:190-195)
-                if (!identity) {
-                    bo = xf_point(B.W, wo);
-                    bd = normalize3(xf_dir(B.W, wd));
-                    tw = signum(obj_t) * len3(xf_point(B.O, bo + bd * obj_t) - wo);
-                }
-                // nearer than the recorded hit, or equally near and earlier in the object list (min_by)
-                if (tw >= 0.0 && tw < DBL_MAX && (rec_obj < 0 || tw < recorded_t || (tw == recorded_t && B.object < rec_obj))) {
-                    // normal / uv of the hit (mesh.rs:97-112 + the Composite's to_world)
-                    const size_t tr = (size_t)B.tri0 + tri;
-                    const double *nb = sc.tri_nrm + tr * 9;
-                    const d3 n0 = mk3(nb[0], nb[1], nb[2]), n1 = mk3(nb[3], nb[4], nb[5]), n2 = mk3(nb[6], nb[7], nb[8]);
-                    double tt = 0.0, u = 0.0, v = 0.0;
-                    tri_hit(sc.tris + tr * 9, bo, bd, tt, u, v);
-                    d3 nl = B.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
-                    d3 n = identity ? nl : normalize3(xf_normal(B.W, nl));
-                    hit.t[fri] = tw;
-                    hit.n[0][fri] = n.x;
-                    hit.n[1][fri] = n.y;
-                    hit.n[2][fri] = n.z;
-                    hit.uv[0][fri] = u;
-                    hit.uv[1][fri] = v;
-                    hit.obj[fri] = B.object;
-                    if (primary_ids) primary_ids[ray_slot(q, fri)] = B.object;
-                }
-            }
-            nd -= batch;
-        }
         PF_MARK(pf_d);
         if (nothing_left) break;
 #ifdef RT_MESH_PROF

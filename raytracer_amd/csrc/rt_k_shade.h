@@ -6,9 +6,71 @@
 #include "rt_k_material.h"
 #include "rt_k_mesh.h"
 
+// k_mesh_one's result for a mesh record - the nearest triangle of the scene's one mesh job, t in object space - merged
+// into the record's hit `h` (the nearest hit among the other objects) for the world ray (wo, wd): Intersection::to_world's
+// t (system.rs:190-195), min_by's order (nearer, or equally near and earlier in the object list), then normal and uv of
+// the hit (mesh.rs:97-112 + the Composite's to_world).  The expressions are k_mesh's (its job loop and its write-back),
+// on the same inputs.  Returns whether the mesh replaced the hit.
+RT_DEV bool mesh_one_finish(const DevScene &sc, d3 wo, d3 wd, double obj_t, uint32_t tri, HitRec &h)
+{
+    const DevMeshJob &B = sc.jobs[0];
+    d3 bo = wo, bd = wd;
+    double tw = obj_t;
+    if (!B.identity) {
+        bo = xf_point(B.W, wo);
+        bd = normalize3(xf_dir(B.W, wd));
+        tw = signum(obj_t) * len3(xf_point(B.O, bo + bd * obj_t) - wo);
+    }
+    if (!(tw >= 0.0 && tw < DBL_MAX && (h.obj < 0 || tw < h.t || (tw == h.t && B.object < h.obj)))) return false;
+    const size_t tr = (size_t)B.tri0 + tri;
+    const double *nb = sc.tri_nrm + tr * 9;
+    const d3 n0 = mk3(nb[0], nb[1], nb[2]), n1 = mk3(nb[3], nb[4], nb[5]), n2 = mk3(nb[6], nb[7], nb[8]);
+    double tt = 0.0, u = 0.0, v = 0.0;
+    tri_hit(sc.tris + tr * 9, bo, bd, tt, u, v);
+    d3 nl = B.smooth ? normalize3((1.0 - u - v) * n0 + u * n1 + v * n2) : normalize3(n0 + n1 + n2);
+    h.n = B.identity ? nl : normalize3(xf_normal(B.W, nl));
+    h.t = tw;
+    h.u = u;
+    h.v = v;
+    h.obj = B.object;
+    return true;
+}
+
+// rt_trace_rays: the merged hit of mesh record j back to its ray's slot in the per-ray hit buffer (res_tri != null:
+// k_mesh_one walked the records and left the merge to mesh_one_finish)
+__global__ void k_copy_mesh_hits(DevScene sc, RayQueue mq, HitBuf mqh, const uint32_t *mesh_count, HitBuf hit, const double *res_t,
+                                 const uint32_t *res_tri)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *mesh_count) return;
+    const uint32_t i = mq.slot[j];
+    HitRec h;
+    h.t = mqh.t[j];
+    h.n = mk3(mqh.n[0][j], mqh.n[1][j], mqh.n[2][j]);
+    h.u = mqh.uv[0][j];
+    h.v = mqh.uv[1][j];
+    h.obj = mqh.obj[j];
+    if (res_tri) {
+        const uint32_t tri = res_tri[j];
+        if (tri != 0xFFFFFFFFu)
+            (void)mesh_one_finish(sc, mk3(mq.o[0][j], mq.o[1][j], mq.o[2][j]), mk3(mq.d[0][j], mq.d[1][j], mq.d[2][j]), res_t[j], tri, h);
+    }
+    hit.t[i] = h.t;
+    hit.n[0][i] = h.n.x;
+    hit.n[1][i] = h.n.y;
+    hit.n[2][i] = h.n.z;
+    hit.uv[0][i] = h.u;
+    hit.uv[1][i] = h.v;
+    hit.obj[i] = h.obj;
+}
+
+// The mesh records after the mesh kernel: hit_color + scatter, survivors appended behind k_intersect's.  res_tri != null:
+// the mesh kernel was k_mesh_one, which leaves the merge of its triangle into the record's hit to this kernel
+// (mesh_one_finish); primary_ids (depth 0 of stratum 0 only) then takes the mesh object's id here.
 template <bool SLDS>
 __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
-                                                     RayQueue qout, uint32_t *count_out, double *fb, PassParams pp)
+                                                     RayQueue qout, uint32_t *count_out, double *fb, PassParams pp,
+                                                     const double *res_t, const uint32_t *res_tri, int32_t *primary_ids)
 {
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
@@ -23,6 +85,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
         uint32_t slot = 0, pixel = 0;
         HitRec h;
         h.obj = i < count ? hit.obj[i] : RT_HIT_PADDING;
+        const uint32_t tri = (res_tri && i < count) ? res_tri[i] : 0xFFFFFFFFu;
         if (h.obj != RT_HIT_PADDING) {
             h.t = 0.0;
             h.n = mk3(0, 0, 0);
@@ -35,7 +98,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
                 slot = qin.slot[i];
                 pixel = qin.pixel[i];
                 thr = mk3(qin.thr[0][i], qin.thr[1][i], qin.thr[2][i]);
-                if (h.obj >= 0) {
+                if (h.obj >= 0 || tri != 0xFFFFFFFFu) {
                     o = mk3(qin.o[0][i], qin.o[1][i], qin.o[2][i]);
                     d = mk3(qin.d[0][i], qin.d[1][i], qin.d[2][i]);
                 }
@@ -46,6 +109,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
                 h.u = hit.uv[0][i];
                 h.v = hit.uv[1][i];
             }
+            if (tri != 0xFFFFFFFFu && mesh_one_finish(sc, o, d, res_t[i], tri, h) && primary_ids) primary_ids[slot] = h.obj;
             d3 X;
             alive = shade_one(sc, o, d, thr, pixel, h, pp, bg, X);
             if (!alive) {

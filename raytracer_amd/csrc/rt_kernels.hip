@@ -72,6 +72,8 @@ struct Workspace {
     RayQueue q[2]; // ping-pong ray queues
     RayQueue mq;   // mesh record queue, ray part: the rays that have to visit a mesh this pass, by queue position
     HitBuf mqh;    // mesh record queue, hit part: their nearest hit so far (k_mesh merges the triangles' into it)
+    double *mres_t = nullptr;     // k_mesh_one's result per mesh record: t in object space,
+    uint32_t *mres_tri = nullptr; // triangle (~0: none; set by k_intersect with the record); k_shade merges it
     uint32_t *d_counts = nullptr;   // 2 x (depth_cap + 2) + 2: live rays per depth, mesh-queue lengths per depth, k_tail's lane totals
     uint32_t *d_work = nullptr;     // k_mesh's block cursors: 2 structures x RT_MESH_CURSORS, 64 bytes apart; zeroed by every k_intersect
     uint32_t *d_guards = nullptr;   // 8
@@ -85,8 +87,8 @@ struct Workspace {
 // process ends; the name below is only a host-side handle for hipGetSymbolAddress - host code uses the
 // per-device pointer obtained at set-up (rt_scene_create), never the name.
 // RT_NOALLOC_MAX_SLOTS, RT_NOALLOC_MAX_DEPTH: rt_api.h
-#define RT_WS_BYTES_PER_SLOT 292u // carve_workspace: 33 f64 + 7 u32 arrays (two ray queues of 80 B, mesh records of 132 B)
-#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 8192u) // 95.8 MiB
+#define RT_WS_BYTES_PER_SLOT 304u // carve_workspace: 34 f64 + 8 u32 arrays (two ray queues of 80 B, mesh records of 132 + 12 B)
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 8192u) // 99.8 MiB
 static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
 #define RT_MAX_DEVICES 64
 static void *g_noalloc_ptr[RT_MAX_DEVICES]; // device address of rt_noalloc_scratch, per device
@@ -166,6 +168,7 @@ static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Worksp
     o.mqh.t = (double *)take(n, 8);
     for (int c = 0; c < 3; ++c) o.mqh.n[c] = (double *)take(n, 8);
     for (int c = 0; c < 2; ++c) o.mqh.uv[c] = (double *)take(n, 8);
+    o.mres_t = (double *)take(n, 8);
     for (RayQueue *rq : queues) {
         rq->slot = (uint32_t *)take(n, 4);
         rq->pixel = (uint32_t *)take(n, 4);
@@ -176,6 +179,7 @@ static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Worksp
         std::memset(&rq->g, 0, sizeof(rq->g));
     }
     o.mqh.obj = (int32_t *)take(n, 4);
+    o.mres_tri = (uint32_t *)take(n, 4);
     o.d_counts = (uint32_t *)take(2 * ((size_t)max_depth + 2) + 2, 4);
     o.d_work = (uint32_t *)take(2 * RT_MESH_CURSORS * 16, 4);
     o.d_guards = (uint32_t *)take(8, 4);
@@ -419,7 +423,7 @@ static int check_options(const rt_options *o)
 // visit are shaded there and then), then for the mesh records it queued k_mesh | k_mesh_brute (the triangles)
 // and k_shade.  Survivors of both go to `qout` / `count_out`, finished paths to `fb`.
 // fused == false (rt_trace_rays): no shading; every ray's hit record ends up in `hit_all`.
-// Returns 1 when the grid walk (k_mesh) ran, 0 otherwise.  Stage events (if any): ev_mid1 after k_intersect,
+// Returns 1 when the grid / kd walk (k_mesh) ran, 2 when k_mesh_one did, 0 otherwise.  Stage events (if any): ev_mid1 after k_intersect,
 // ev_mid2 after the mesh kernel.
 static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q,
                             const uint32_t *count_ptr, uint32_t *mesh_count, const PassParams &pp, int32_t *ids,
@@ -430,14 +434,18 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     if (gb < 1) gb = 1;
     if (gb > 256 * 8) gb = 256 * 8; // 256 CUs x 8 blocks, grid-stride beyond that
     dim3 grid((uint32_t)gb), block(RT_ISECT_BLOCK);
+    // the scene's one grid job goes to k_mesh_one, which leaves its triangle beside the record for k_shade to merge
+    // (only long queues: short ones go to k_mesh_brute, which writes the hit record itself)
+    const bool one = s->has_mesh && s->any_grid && s->mesh_pool_lds_bytes != 0u &&
+                     (uint64_t)live * s->n_mesh_tris > (uint64_t)RT_BRUTE_MAX_TESTS;
 #define LAUNCH_I(C, M, T, L)                                                                                           \
     do {                                                                                                               \
         if (fused)                                                                                                     \
             hipLaunchKernelGGL((k_intersect<C, M, T, L, true>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q,   \
-                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work); \
+                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, one ? w.mres_tri : nullptr); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_intersect<C, M, T, L, false>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q,  \
-                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work); \
+                               count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, one ? w.mres_tri : nullptr); \
     } while (0)
     // scenes whose tables do not fit LDS (scene_lds_bytes == 0) run the one variant that reads them from memory,
     // which is the most general one
@@ -479,7 +487,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
                        mesh_count, w.d_work + (KD ? RT_MESH_CURSORS * 16 : 0), w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
             // one launch per structure in use: each instantiation walks its own meshes and passes the others by
             // (the record carries the nearest hit from one launch to the next)
-            if (s->any_grid && s->mesh_pool_lds_bytes != 0u) {
+            if (one) {
                 // the scene's one job: k_mesh_one (as many workgroups as the chip holds; they take blocks until the
                 // queue is empty)
                 const uint64_t per_pool_wg = RT_MESH_MIN_BLOCK * (RT_POOL_LANES / 64);
@@ -487,7 +495,8 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
                 if (pb < 1) pb = 1;
                 if (pb > max_wgs) pb = max_wgs;
                 hipLaunchKernelGGL(k_mesh_one, dim3((uint32_t)pb), dim3(RT_POOL_LANES), s->mesh_pool_lds_bytes, st, s->dev, w.mq,
-                                   mesh_count, w.d_work, w.mqh, ids, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+                                   mesh_count, w.d_work, w.mqh, w.mres_t, w.mres_tri, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+                walked = 2;
             } else if (s->any_grid) {
                 if (jobs_lds)
                     LAUNCH_M(false, true, s->mesh_lds_bytes);
@@ -501,7 +510,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
                     LAUNCH_M(true, false, s->mesh_kd_lds_bytes);
             }
 #undef LAUNCH_M
-            walked = 1;
+            if (!walked) walked = 1;
         }
     }
     if (ev_mid2) (void)hipEventRecord(ev_mid2, st);
@@ -510,12 +519,14 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             // the mesh records: hit_color + scatter, survivors appended behind k_intersect's
             if (scene_lds_bytes(s->dev) != 0u)
                 hipLaunchKernelGGL(k_shade<true>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st,
-                                   s->dev, w.mq, mesh_count, w.mqh, qout, count_out, fb, pp);
+                                   s->dev, w.mq, mesh_count, w.mqh, qout, count_out, fb, pp, one ? w.mres_t : nullptr,
+                                   one ? w.mres_tri : nullptr, ids);
             else
                 hipLaunchKernelGGL(k_shade<false>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, w.mq,
-                                   mesh_count, w.mqh, qout, count_out, fb, pp);
+                                   mesh_count, w.mqh, qout, count_out, fb, pp, one ? w.mres_t : nullptr, one ? w.mres_tri : nullptr, ids);
         } else {
-            hipLaunchKernelGGL(k_copy_mesh_hits, dim3((live + 255) / 256), dim3(256), 0, st, w.mq, w.mqh, mesh_count, hit_all);
+            hipLaunchKernelGGL(k_copy_mesh_hits, dim3((live + 255) / 256), dim3(256), 0, st, s->dev, w.mq, w.mqh, mesh_count, hit_all,
+                               one ? w.mres_t : nullptr, one ? w.mres_tri : nullptr);
         }
     }
     return walked;
@@ -739,6 +750,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                         if (walked[k]) {
                             local.n_mesh_launches++;
                             local.mesh_rays += mesh_counts[k];
+                            if (walked[k] == 2) local.mesh_one_rays += mesh_counts[k];
                         }
                         local.mesh_records += mesh_counts[k];
                     }
@@ -1221,6 +1233,7 @@ extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, cons
             stats->mesh_rays += st[k].mesh_rays;
             stats->intersect_rays += st[k].intersect_rays;
             stats->mesh_records += st[k].mesh_records;
+            stats->mesh_one_rays += st[k].mesh_one_rays;
             stats->interval_overflow += st[k].interval_overflow;
             for (int g = 0; g < 5; ++g) stats->guards[g] += st[k].guards[g];
             if (st[k].bounce_passes > stats->bounce_passes) stats->bounce_passes = st[k].bounce_passes;

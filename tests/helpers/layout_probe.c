@@ -36,7 +36,7 @@ int main(void)
     S(rt_stats); F(rt_stats, rays); F(rt_stats, primary_rays); F(rt_stats, strata); F(rt_stats, bounce_passes); F(rt_stats, guards);
     F(rt_stats, interval_overflow); F(rt_stats, ms_device); F(rt_stats, ms_raygen); F(rt_stats, ms_intersect); F(rt_stats, ms_shade);
     F(rt_stats, ms_mesh); F(rt_stats, ms_tail); F(rt_stats, n_intersect_launches); F(rt_stats, n_mesh_launches);
-    F(rt_stats, mesh_rays); F(rt_stats, intersect_rays); F(rt_stats, mesh_records); E();
+    F(rt_stats, mesh_rays); F(rt_stats, intersect_rays); F(rt_stats, mesh_records); F(rt_stats, mesh_one_rays); E();
     S(rt_hit); F(rt_hit, t); F(rt_hit, n); F(rt_hit, uv); F(rt_hit, object); F(rt_hit, pad); E();
     S(rt_progress); F(rt_progress, on_stratum); F(rt_progress, on_snapshot); F(rt_progress, min_interval_ms);
     F(rt_progress, reserved); F(rt_progress, user); E();

@@ -29,7 +29,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_capi.rt_options) == 48
     assert C.sizeof(_capi.rt_shape_node) == 16 + 8 * 8 + 2 * 128
     assert C.sizeof(_capi.rt_hit) == 56
-    assert C.sizeof(_capi.rt_stats) == 128
+    assert C.sizeof(_capi.rt_stats) == 136
 
 
 def _c_layout():
