@@ -133,7 +133,9 @@ RT_DEV void block_append2(bool a, bool b, uint32_t *counter_a, uint32_t *counter
 }
 
 #ifndef RT_BLOCK_WIDE
-#define RT_BLOCK_WIDE 1024 // ray generation and shading: light on registers, heavy on queue appends
+#define RT_BLOCK_WIDE 256 // k_shade: one atomic per workgroup and append.  1024 (a quarter of the atomics) measures the same
+                          // with the GPU to itself; beside other frames' kernels a 256-lane workgroup finds room on a CU
+                          // sooner than a 1024-lane one: 4K mesh.scene, 4 frames in flight, 2.29 against 2.34 ms per frame
 #endif
 
 // The scene's small tables (objects, leaves, meshes, materials, textures) are read by every ray

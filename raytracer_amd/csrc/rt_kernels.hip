@@ -5,10 +5,14 @@
 //
 //   (primary rays: camera + jitter, system.rs:237-242, 57-66, regenerated inside the depth-0 kernels)
 //   repeat for depth = 0 .. max_depth-1 while rays remain:
-//     k_intersect nearest hit over the object list        (system.rs:122-133, shapes/*)   rt_k_intersect.h
-//     k_mesh      ... merged with the meshes' triangles   (mesh.rs, composite.rs)        rt_k_mesh.h
-//     k_shade     emit / scatter / terminate, compacting  (system.rs:112-120,135-142,    rt_k_shade.h
-//                 survivors into the other ray queue       materials/*, texture.rs)
+//     k_intersect nearest hit over the object list except (system.rs:122-133, shapes/*)   rt_k_intersect.h
+//                 the triangles; rays with no mesh to visit are shaded here (as k_shade), the others are queued
+//                 as mesh records (ray + hit so far)
+//     k_mesh_one  the mesh records against the triangles:  (mesh.rs, composite.rs)        rt_k_mesh_pool.h
+//     | k_mesh    grid walk (one mesh job | general, or kd-tree), or one wave per ray for    rt_k_mesh.h,
+//     | k_mesh_brute  short queues                                                            rt_k_mesh_grid_round.inc
+//     k_shade     the mesh records: emit / scatter / terminate, (system.rs:112-120,135-142,  rt_k_shade.h
+//                 survivors into the other ray queue            materials/*, texture.rs)     rt_k_material.h
 //   k_tail        the last few thousand paths, all their remaining segments in one launch
 // This file: the host side - scene upload, workspace, the pass loop, the C ABI entry points.
 //
@@ -385,7 +389,7 @@ static uint32_t grid_for_wide(uint64_t n)
 {
     uint64_t b = (n + RT_BLOCK_WIDE - 1) / RT_BLOCK_WIDE;
     if (b < 1) b = 1;
-    if (b > 256 * 2) b = 256 * 2;
+    if (b > 256 * 2 * (1024 / RT_BLOCK_WIDE)) b = 256 * 2 * (1024 / RT_BLOCK_WIDE); // 2048 lanes per CU, grid-stride beyond
     return (uint32_t)b;
 }
 
