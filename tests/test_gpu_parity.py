@@ -905,3 +905,24 @@ def test_mesh_kernels_agree(rt, monkeypatch):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
     for k in ("object", "t", "n", "uv"):
         assert np.array_equal(out[0][3][k], out[1][3][k]), k
+
+
+def test_stats_name_the_mesh_kernel(rt, monkeypatch):
+    """rt_stats.mesh_one_rays: all of mesh_rays in a scene with one mesh job (k_mesh_one walked the grid), none when the
+    scene has two jobs (two mesh objects: k_mesh) or when RT_MESH_POOL=0 keeps k_mesh; mesh_records counts every ray that
+    went through the mesh queue either way."""
+    o = rt.Options(width=320, height=200, samples=1, seed=3, stage_times=True)  # the per-kernel fields of rt_stats
+    one = rt.DeviceScene(rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS))
+    _, _, st = one.render(o)
+    assert st.mesh_rays > 0 and st.mesh_one_rays == st.mesh_rays and st.mesh_records >= st.mesh_rays
+    text = ('camera { origin <0, 1, 6> look_at <0, 0.5, 0> }\n'
+            'object "light" { sphere { origin <4, 6, 3> radius 2 } material { diffuse_light intensity 4 texture { solid color white } } }\n'
+            'object "a" { mesh { file "LinkedTorus.obj" transform { translate <-1.5, 0, 0> } } material { lambertian texture { solid color white } } }\n'
+            'object "b" { mesh { file "LinkedTorus.obj" transform { translate <1.5, 0, 0> } } material { lambertian texture { solid color white } } }\n')
+    two = rt.DeviceScene(rt.parse(o, text, parity.ASSETS))
+    _, _, st2 = two.render(o)
+    assert st2.mesh_rays > 0 and st2.mesh_one_rays == 0
+    monkeypatch.setenv("RT_MESH_POOL", "0")
+    off = rt.DeviceScene(rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS))
+    _, _, st3 = off.render(o)
+    assert st3.mesh_rays == st.mesh_rays and st3.mesh_one_rays == 0 and st3.rays == st.rays
