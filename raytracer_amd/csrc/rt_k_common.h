@@ -79,6 +79,20 @@ struct PassParams {
 
 RT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// A finished path's colour goes to its pixel.  Every slot takes at most one path per launch, so the sum is the same
+// whichever unit adds: the L2's f64 add does (global_atomic_add_f64, nothing returned), so the wave has no load to
+// wait for; and an exact zero - a path that ends on a black background - is not added at all (the sums start at
+// +0.0 and never hold -0.0, so x + 0 is x bit for bit).
+RT_DEV void fb_add(double *px, double r, double g, double b)
+{
+    if (r != 0.0 || g != 0.0 || b != 0.0) {
+        unsafeAtomicAdd(px + 0, r);
+        unsafeAtomicAdd(px + 1, g);
+        unsafeAtomicAdd(px + 2, b);
+    }
+}
+
+
 // Append with one atomic per workgroup: a single counter word takes about 90 atomics per
 // microsecond on this chip, so a per-wave atomic caps a pass at ~6 G appended rays/s; with
 // 1024-thread workgroups the counter is out of the picture.  Called by every thread of the

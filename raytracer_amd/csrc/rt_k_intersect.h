@@ -319,10 +319,7 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
                 d3 X;
                 alive = shade_one(sc, o, d, thr, pixel, h, pp, bg, X);
                 if (!alive) {
-                    double *px = fb + (size_t)slot * 3;
-                    px[0] += thr.x * X.x;
-                    px[1] += thr.y * X.y;
-                    px[2] += thr.z * X.z;
+                    fb_add(fb + (size_t)slot * 3, thr.x * X.x, thr.y * X.y, thr.z * X.z);
                 }
             }
         }

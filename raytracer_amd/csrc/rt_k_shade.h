@@ -113,10 +113,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
             d3 X;
             alive = shade_one(sc, o, d, thr, pixel, h, pp, bg, X);
             if (!alive) {
-                double *px = fb + (size_t)slot * 3;
-                px[0] += thr.x * X.x;
-                px[1] += thr.y * X.y;
-                px[2] += thr.z * X.z;
+                fb_add(fb + (size_t)slot * 3, thr.x * X.x, thr.y * X.y, thr.z * X.z);
             }
         }
         uint32_t at = block_append(alive, count_out, append_lds);
@@ -182,10 +179,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
             const bool alive = shade_one(sc, o, d, thr, pixel, h, p, bg, X);
             if (!alive) {
                 if (writer) {
-                    double *px = fb + (size_t)slot * 3;
-                    px[0] += thr.x * X.x;
-                    px[1] += thr.y * X.y;
-                    px[2] += thr.z * X.z;
+                    fb_add(fb + (size_t)slot * 3, thr.x * X.x, thr.y * X.y, thr.z * X.z);
                 }
                 break;
             }
