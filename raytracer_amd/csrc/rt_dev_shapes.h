@@ -357,13 +357,25 @@ RT_DEV void leaf_surface(const DevLeaf &L, const LeafRay &ry, d3 q, uint32_t tag
         }
         break;
     }
-    case DL_PLANE:
+    case DL_PLANE: {
+        // plane.rs:62-79; the uv basis of either side is a constant of the plane, worked out by the flattener
+        // (plane_constants: dev_plane_uv's own operations on N and on N * -1.0)
+        const d3 N = mk3(p[3], p[4], p[5]);
+        const bool back = dot3(ry.d, N) > 0.0;
+        n = back ? N * -1.0 : N;
+        if (need_uv) {
+            const double *b = p + (back ? 15 : 9);
+            d3 op = q - mk3(p[0], p[1], p[2]);
+            u = dot3(mk3(b[0], b[1], b[2]), op);
+            v = dot3(mk3(b[3], b[4], b[5]), op);
+        }
+        break;
+    }
     case DL_RECT_XY:
     case DL_RECT_XZ:
     case DL_RECT_ZY: {
         // plane.rs:62-79
-        d3 N = L.kind == DL_PLANE ? mk3(p[3], p[4], p[5])
-                                  : axis_vec(L.kind == DL_RECT_XY ? 2 : (L.kind == DL_RECT_XZ ? 1 : 0), p[3]);
+        d3 N = axis_vec(L.kind == DL_RECT_XY ? 2 : (L.kind == DL_RECT_XZ ? 1 : 0), p[3]);
         n = (dot3(ry.d, N) > 0.0) ? N * -1.0 : N;
         if (need_uv) {
             d3 bu, bv;

@@ -320,6 +320,53 @@ struct Flattener {
         }
     }
 
+    // What every hit of a plane would work out again (plane.rs:62-79, system.rs:196): the unit world normal and the
+    // uv basis, one set for the side the normal points to and one for the other (n = N * -1.0).  The same operations in
+    // the same order as the kernels' normalize3 / cross3 / xf_normal / dev_plane_uv (rt_dev_math.h, rt_dev_shapes.h),
+    // so the constants are the bits a per-hit evaluation would give.  p[6..8] / p[21..23]: world normal front / back;
+    // p[9..14] / p[15..20]: bu, bv front / back.
+    static void unit3(const double a[3], double r[3])
+    {
+        const double l2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        if (l2 > 0.0) {
+            const double inv = 1.0 / std::sqrt(l2);
+            for (int k = 0; k < 3; ++k) r[k] = a[k] * inv;
+        } else {
+            for (int k = 0; k < 3; ++k) r[k] = a[k];
+        }
+    }
+    static void cross(const double a[3], const double b[3], double r[3])
+    {
+        r[0] = a[1] * b[2] - a[2] * b[1];
+        r[1] = a[2] * b[0] - a[0] * b[2];
+        r[2] = a[0] * b[1] - a[1] * b[0];
+    }
+    static void plane_constants(DevLeaf &L)
+    {
+        for (int side = 0; side < 2; ++side) {
+            double n[3];
+            for (int k = 0; k < 3; ++k) n[k] = side ? L.p[3 + k] * -1.0 : L.p[3 + k];
+            double w[3];
+            if (L.identity) {
+                for (int k = 0; k < 3; ++k) w[k] = n[k];
+            } else {
+                const double *m = L.W.m;
+                w[0] = n[0] * m[0] + n[1] * m[1] + n[2] * m[2];
+                w[1] = n[0] * m[3] + n[1] * m[4] + n[2] * m[5];
+                w[2] = n[0] * m[6] + n[1] * m[7] + n[2] * m[8];
+            }
+            unit3(w, L.p + (side ? 21 : 6));
+            const double ex[3] = {1.0, 0.0, 0.0}, ey[3] = {0.0, 1.0, 0.0}, ez[3] = {0.0, 0.0, 1.0};
+            double u[3];
+            cross(n, ex, u);
+            if (u[0] * u[0] + u[1] * u[1] + u[2] * u[2] < 1e-6) cross(n, ey, u);
+            if (u[0] * u[0] + u[1] * u[1] + u[2] * u[2] < 1e-6) cross(n, ez, u);
+            double *b = L.p + (side ? 15 : 9);
+            unit3(u, b);
+            cross(n, b, b + 3);
+        }
+    }
+
     // a primitive; returns the leaf index
     int emit_primitive(const rt_shape_node &nd, const Mat4 &W, const Mat4 &O)
     {
@@ -338,6 +385,7 @@ struct Flattener {
         case RT_SHAPE_PLANE: {
             li = push_leaf(DL_PLANE, W, O);
             for (int k = 0; k < 6; ++k) out.leaves[li].p[k] = p[k];
+            plane_constants(out.leaves[li]);
             break;
         }
         case RT_SHAPE_XYRECT:

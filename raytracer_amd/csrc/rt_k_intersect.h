@@ -238,7 +238,13 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
             leaf_surface(L, ry, ql, best_aux, need_uv, nl, u, v);
             // system.rs:196 normalises every world normal; only a plane's own normal can arrive
             // un-normalised (`normal <0, 2, 0>`), every other shape hands over a unit vector
-            n = L.identity ? (L.kind == DL_PLANE ? normalize3(nl) : nl) : normalize3(xf_normal(L.W, nl));
+            if (L.kind == DL_PLANE) {
+                // ... which for a plane is one of two constants (plane_constants in rt_flatten.cpp: the same operations)
+                const double *wn = L.p + ((dot3(ry.d, mk3(L.p[3], L.p[4], L.p[5])) > 0.0) ? 21 : 6);
+                n = mk3(wn[0], wn[1], wn[2]);
+            } else {
+                n = L.identity ? nl : normalize3(xf_normal(L.W, nl));
+            }
             if (CSG && skips) {
                 // ... and the normal misses the skipped nodes' maps, innermost first
                 for (int li = 0; li < ob.n_leaves; ++li) {
