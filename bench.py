@@ -30,9 +30,10 @@ import time
 # One hardware queue per stream that has work at the same time: the frames in flight each own a stream, torch's
 # stream carries the gather, and HIP's default of 4 queues per process would make the fourth frame's stream share
 # one (measured: 4 frames in flight 2.59 ms per frame on 4 queues, 2.31 on 8; 3 frames 2.42 on either).  Read by
-# the HIP runtime when it starts, so it is set before anything touches the GPU; a larger value from the caller stays.
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# the HIP runtime when it starts, so it is set before anything touches the GPU; a value from the caller stays (the
+# profiling scripts export the same 8 before rocprofv3, whose preloaded library may start the runtime first).  The
+# value in effect is recorded in the JSON line's config.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -359,7 +360,7 @@ def main():
             "config": {"workload": "%s.scene %dx%d samples=%d max_depth=50, seed=1+step" %
                                    (args.scene, args.width, args.height, args.samples),
                        "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps,
-                       "frames_in_flight": F},
+                       "frames_in_flight": F, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)},
             "roofline": roof,
             "roofline_valu": valu,
             "kernels": kernels[1:],

@@ -264,6 +264,25 @@ extern "C" {
         stats: *mut rt_stats,
         progress: *const rt_progress,
     ) -> c_int;
+    pub fn rt_render_rgb8(
+        scene: *mut rt_scene,
+        opts: *const rt_options,
+        rgb8: *mut u8,
+        primary_ids: *mut i32,
+        stats: *mut rt_stats,
+        progress: *const rt_progress,
+    ) -> c_int;
+    pub fn rt_render_multi_rgb8(
+        scenes: *const *mut rt_scene,
+        n_devices: u32,
+        opts: *const rt_options,
+        rgb8: *mut u8,
+        primary_ids: *mut i32,
+        stats: *mut rt_stats,
+        progress: *const rt_progress,
+    ) -> c_int;
+    pub fn rt_pinned_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn rt_pinned_free(p: *mut c_void);
     pub fn rt_render_device_noalloc(
         scene: *mut rt_scene,
         opts: *const rt_options,
@@ -555,6 +574,43 @@ impl Scene {
         })?;
         ctx.progress.render_finished(options, &buf);
         Ok((buf, stats))
+    }
+
+    /// `system::render` + `write_render_result_to_file`'s pixel math (`src/main.rs:106`, `201-222`): the frame as
+    /// row-major RGB8, tone-mapped on the GPU by strata + 1; 3 bytes per pixel cross PCIe instead of 24.
+    pub fn render_rgb8(&mut self, options: &Options) -> Result<(Vec<u8>, rt_stats), Error> {
+        let n = (options.width as usize) * (options.height as usize) * 3;
+        let mut buf = vec![0u8; n];
+        let mut stats = rt_stats::default();
+        let opts = options.to_c(0, 1, 0);
+        check(unsafe { rt_render_rgb8(self.handle, &opts, buf.as_mut_ptr(), ptr::null_mut(), &mut stats, ptr::null()) })?;
+        Ok((buf, stats))
+    }
+}
+
+/// Page-locked host memory (`rt_pinned_alloc`) for frames that leave the GPU at the link's speed.
+pub struct PinnedBuf {
+    ptr: *mut c_void,
+    bytes: usize,
+}
+
+impl PinnedBuf {
+    pub fn new(bytes: usize) -> Result<PinnedBuf, Error> {
+        let mut ptr: *mut c_void = ptr::null_mut();
+        check(unsafe { rt_pinned_alloc(bytes, &mut ptr) })?;
+        Ok(PinnedBuf { ptr, bytes })
+    }
+    pub fn as_mut_ptr<T>(&mut self) -> *mut T {
+        self.ptr as *mut T
+    }
+    pub fn len(&self) -> usize {
+        self.bytes
+    }
+}
+
+impl Drop for PinnedBuf {
+    fn drop(&mut self) {
+        unsafe { rt_pinned_free(self.ptr) }
     }
 }
 

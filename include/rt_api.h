@@ -199,6 +199,7 @@ typedef struct rt_stats {
     double ms_shade;     /* k_shade: the shading of the rays that went through the mesh record queue  */
     double ms_mesh;      /* k_mesh / k_mesh_brute: the rays queued for a mesh   */
     double ms_tail;      /* k_tail: the last few paths, all remaining bounces   */
+    /* launches and rays per stage: always filled (the times above only with RT_FLAG_STAGE_TIMES) */
     uint32_t n_intersect_launches; /* k_intersect launches that had rays        */
     uint32_t n_mesh_launches;      /* k_mesh (grid walk) launches               */
     uint64_t mesh_rays;            /* rays those k_mesh launches walked         */
@@ -279,22 +280,47 @@ int rt_render_device_progress(rt_scene *scene, const rt_options *opts, double *d
  * are spread over the GPUs (tile k to scenes[k % n_devices], opts->shard_* are ignored), each GPU runs its
  * wavefront loop from its own host thread, and the finished tiles are gathered over xGMI to scenes[0]'s GPU,
  * which scatters them into the row-major image (combine_renderbuf's counterpart) and hands it to the host.
+ * Every peer pushes its shard on its own stream into its own region of the first GPU's buffer, so the copies
+ * run over the peers' links at the same time; one launch then scatters all regions.
  * scenes[k]: the same description created with GPU k current (rt_scene_create); the same device may appear
- * more than once.  rgb_sum: H*W*3 doubles, host; primary_ids: H*W or NULL; stats: rays and counters summed
- * over the devices, ms_device of the slowest; progress (may be NULL): on_stratum when every GPU has finished
- * that stratum, on_snapshot with the row-major image assembled from all shards. */
+ * more than once, each time through an rt_scene of its own (one scene serves one render at a time: the same
+ * pointer twice is RT_ERR_INVALID).  rgb_sum: H*W*3 doubles, host (page-locked memory, rt_pinned_alloc, takes
+ * the frame at the link's speed); primary_ids: H*W or NULL; stats: rays and counters summed over the devices,
+ * ms_device of the slowest; progress (may be NULL): on_stratum when every GPU has finished that stratum,
+ * on_snapshot with the row-major image assembled from all shards.  A device that fails (its render, a progress
+ * snapshot, its copy) makes the call return that device's code with its message in rt_last_error().  Each
+ * scene keeps a stream and a host thread for these calls.  The calling thread drives scenes[0]'s GPU. */
 int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts, double *rgb_sum,
                     int32_t *primary_ids, rt_stats *stats, const rt_progress *progress);
 
-/* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same outputs (bit for
- * bit), but the wavefront state (ray queues, hit records, mesh queue, counters) lives in a static device
- * array of the library (99.8 MiB per GPU the library runs on, held until the process ends) instead of a
- * workspace the scene allocates and grows, and the call makes no hipMalloc / hipFree / hipHostMalloc /
- * hipEventCreate: everything else it needs was set up by rt_scene_create.  Limits: a shard of at most
+/* system::render followed by write_render_result_to_file's pixel math (main.rs:106, 201-222), for a host that
+ * wants the image and not the sums: the frame is tone-mapped on the GPU by strata + 1 (the reference's divisor,
+ * SURVEY Q1) and handed over as H*W*3 bytes, row-major RGB8 - 3 bytes per pixel across PCIe instead of 24.
+ * primary_ids, stats, progress may be NULL; progress snapshots are row-major RGB8 as well. */
+int rt_render_rgb8(rt_scene *scene, const rt_options *opts, uint8_t *rgb8, int32_t *primary_ids, rt_stats *stats,
+                   const rt_progress *progress);
+/* The same over n_devices GPUs (rt_render_multi's arguments; the gathered frame is tone-mapped on scenes[0]'s GPU). */
+int rt_render_multi_rgb8(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts, uint8_t *rgb8,
+                         int32_t *primary_ids, rt_stats *stats, const rt_progress *progress);
+
+/* Page-locked host memory for the outputs of rt_render / rt_render_rgb8 / rt_render_multi (hipHostMalloc): the
+ * copy out of the GPU then runs at the link's speed instead of through a staging buffer.  No counterpart in the
+ * reference (its frame buffer never leaves the process).  Free with rt_pinned_free. */
+int rt_pinned_alloc(size_t bytes, void **out);
+void rt_pinned_free(void *p);
+
+/* rt_render_device for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc,
+ * processes whose device memory is spoken for.  No counterpart in the reference.  Same arguments, same
+ * outputs (bit for bit), but the wavefront state (ray queues, hit records, mesh queue, counters) lives in a
+ * static device array of the library (99.8 MiB per GPU the library runs on, held until the process ends)
+ * instead of a workspace the scene allocates and grows, and the call makes no hipMalloc / hipFree /
+ * hipHostMalloc / hipEventCreate: everything else it needs was set up by rt_scene_create.  Like
+ * rt_render_device it drives the bounce passes from the host: it reads queue lengths back and synchronises
+ * `stream` before it returns, so it cannot run under HIP stream capture.  Limits: a shard of at most
  * RT_NOALLOC_MAX_SLOTS ray slots (rt_shard_pixels(opts); 640 x 480 fits) and max_depth <=
- * RT_NOALLOC_MAX_DEPTH, beyond which it returns RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's
- * array: calls that overlap on one GPU (two streams, two scenes, two threads) race. */
+ * RT_NOALLOC_MAX_DEPTH, beyond which it returns RT_ERR_UNSUPPORTED.  Every call on a GPU works in that GPU's
+ * one array: a call made while another is running on the same GPU (two streams, two scenes, two threads)
+ * returns RT_ERR_INVALID; calls from other processes are not seen and race. */
 #define RT_NOALLOC_MAX_SLOTS (84u * 4096u)
 #define RT_NOALLOC_MAX_DEPTH 64u
 int rt_render_device_noalloc(rt_scene *scene, const rt_options *opts, double *d_rgb_sum, int32_t *d_primary_ids,

@@ -32,7 +32,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RT_HD __host__ __device__ inline
 #else
 #define RT_HD static inline
@@ -55,7 +55,8 @@ RT_HD void rt_philox_mulhilo(uint32_t a, uint32_t b, uint32_t *hi, uint32_t *lo)
 }
 
 /* Philox4x32 with 10 rounds (Salmon et al., SC'11); known-answer vectors in
- * tests/golden/philox_kat.json. */
+ * tests/golden/reference_unit_vectors.json ("philox4x32_10": Random123's kat_vectors), checked by
+ * tests/test_oracle_golden.py. */
 RT_HD rt_rng_block rt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
     for (int r = 0; r < 10; ++r) {

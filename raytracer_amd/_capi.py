@@ -116,6 +116,12 @@ SIGNATURES = {
                                             C.POINTER(rt_stats), C.c_void_p, C.POINTER(rt_progress)]),
     "rt_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rt_options), C.POINTER(C.c_double),
                                   C.POINTER(C.c_int32), C.POINTER(rt_stats), C.POINTER(rt_progress)]),
+    "rt_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                                 C.POINTER(rt_stats), C.POINTER(rt_progress)]),
+    "rt_render_multi_rgb8": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rt_options), C.POINTER(C.c_uint8),
+                                       C.POINTER(C.c_int32), C.POINTER(rt_stats), C.POINTER(rt_progress)]),
+    "rt_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rt_pinned_free": (None, [C.c_void_p]),
     "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_options), C.c_void_p, C.c_void_p,
                                            C.POINTER(rt_stats), C.c_void_p]),
     "rt_shard_pixels": (C.c_uint64, [C.POINTER(rt_options)]),

@@ -266,12 +266,64 @@ __global__ void k_unshard(rt_shard_geom g, uint32_t rank, uint32_t n_slots, cons
     }
 }
 
-__global__ void k_iota(uint32_t n, uint32_t *slot, uint32_t *pixel, double *t0, double *t1, double *t2)
+// The same for all shards of a frame at once (rt_render_multi): their buffers lie one after the other in rank
+// order, `shards_*` is the first.  Tiles are dealt round-robin, so the first n_tiles % N shards own one tile more
+// than the others and a slot's shard follows from its position.
+__global__ void k_unshard_all(rt_shard_geom g, uint32_t total_slots, const double *shards_rgb, double *full_rgb,
+                              const int32_t *shards_ids, int32_t *full_ids)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        slot[i] = i;
-        pixel[i] = i;
-        t0[i] = t1[i] = t2[i] = 1.0;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_slots) return;
+    const uint32_t gt = i / g.tile_px, j = i - gt * g.tile_px;
+    const uint32_t base = g.n_tiles / g.shard_count, rem = g.n_tiles % g.shard_count;
+    uint32_t rank, local_tile;
+    if (gt < rem * (base + 1u)) {
+        rank = gt / (base + 1u);
+        local_tile = gt - rank * (base + 1u);
+    } else { // base >= 1 here: a shard without tiles has no slots
+        const uint32_t r = gt - rem * (base + 1u);
+        rank = rem + r / base;
+        local_tile = r % base;
     }
+    uint32_t x, y;
+    if (rt_shard_decode(&g, rank, local_tile * g.tile_px + j, &x, &y)) {
+        const size_t p = (size_t)y * g.width + x;
+        if (shards_rgb && full_rgb) {
+            full_rgb[p * 3 + 0] = shards_rgb[(size_t)i * 3 + 0];
+            full_rgb[p * 3 + 1] = shards_rgb[(size_t)i * 3 + 1];
+            full_rgb[p * 3 + 2] = shards_rgb[(size_t)i * 3 + 2];
+        }
+        if (shards_ids && full_ids) full_ids[p] = shards_ids[i];
+    }
+}
+
+// rt_trace_rays: the caller's interleaved rays (xyz, xyz, ...) into queue entries 0 .. n-1, ray i keyed as pixel i
+__global__ void k_rays_in(uint32_t n, const double *__restrict__ origins, const double *__restrict__ directions, RayQueue q)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < 3; ++c) {
+        q.o[c][i] = origins[(size_t)i * 3 + c];
+        q.d[c][i] = directions[(size_t)i * 3 + c];
+        q.thr[c][i] = 1.0;
+    }
+    q.slot[i] = i;
+    q.pixel[i] = i;
+}
+
+// ... and the per-ray hit records out as rt_hit structs
+__global__ void k_hits_out(uint32_t n, HitBuf hit, rt_hit *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rt_hit h;
+    h.t = hit.t[i];
+    h.n[0] = hit.n[0][i];
+    h.n[1] = hit.n[1][i];
+    h.n[2] = hit.n[2][i];
+    h.uv[0] = hit.uv[0][i];
+    h.uv[1] = hit.uv[1][i];
+    h.object = hit.obj[i];
+    h.pad = 0;
+    out[i] = h;
 }

@@ -34,6 +34,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -96,6 +97,7 @@ struct Workspace {
 static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
 #define RT_MAX_DEVICES 64
 static void *g_noalloc_ptr[RT_MAX_DEVICES]; // device address of rt_noalloc_scratch, per device
+static std::atomic<int> g_noalloc_busy[RT_MAX_DEVICES]; // a call is using that device's array
 
 // once per device, with that device current
 static int noalloc_setup(int device)
@@ -109,6 +111,20 @@ static int noalloc_setup(int device)
     g_noalloc_ptr[device] = p;
     return RT_OK;
 }
+
+// A host thread a scene keeps for rt_render_multi: it drives this scene's GPU while the calling thread drives the
+// first one's.  Started on first use, joined when the scene is destroyed.
+struct SceneWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool pending = false, finished = false, quit = false;
+    ~SceneWorker();
+    void submit(std::function<void()> f);
+    void wait();
+    void loop();
+};
 
 struct rt_scene {
     int device = 0;
@@ -136,6 +152,10 @@ struct rt_scene {
     // progress snapshots: tone-mapped RGB8 on the device and in pinned host memory
     uint8_t *snap_d = nullptr, *snap_h = nullptr;
     size_t snap_cap = 0; // bytes
+    // rt_render_multi: this scene's stream, its "shard pushed to the root" event and its host thread, kept between calls
+    hipStream_t multi_stream = nullptr;
+    hipEvent_t multi_done = nullptr;
+    SceneWorker *worker = nullptr;
 };
 
 template <typename T> static int upload(rt_scene *s, const std::vector<T> &v, const T **out)
@@ -363,6 +383,9 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
 extern "C" void rt_scene_destroy(rt_scene *s)
 {
     if (!s) return;
+    delete s->worker; // joins the thread
+    if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
+    if (s->multi_done) (void)hipEventDestroy(s->multi_done);
     for (void *p : s->allocs) (void)hipFree(p);
     free_workspace(s);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
@@ -736,6 +759,19 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     if (lane_totals[0] && lane_totals[1] + 1 > levels) levels = lane_totals[1] + 1;
                 }
                 if (levels > local.bounce_passes) local.bounce_passes = levels; // (strata share the levels)
+                // launches and rays per stage (the counts have come back anyway); times only with RT_FLAG_STAGE_TIMES
+                for (uint32_t k = 0; k < passes; ++k) {
+                    if (s->h_pinned[k]) {
+                        local.n_intersect_launches++; // passes that had rays
+                        local.intersect_rays += s->h_pinned[k];
+                    }
+                    if (walked[k]) {
+                        local.n_mesh_launches++;
+                        local.mesh_rays += mesh_counts[k];
+                        if (walked[k] == 2) local.mesh_one_rays += mesh_counts[k];
+                    }
+                    local.mesh_records += mesh_counts[k];
+                }
                 if (stage_times) {
                     float ms_k = 0.f;
                     HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[0], s->evp[1]));
@@ -747,16 +783,6 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                         local.ms_mesh += ms_k;
                         HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[3 + 4 * k], s->evp[4 + 4 * k]));
                         local.ms_shade += ms_k;
-                        if (s->h_pinned[k]) {
-                            local.n_intersect_launches++; // passes that had rays
-                            local.intersect_rays += s->h_pinned[k];
-                        }
-                        if (walked[k]) {
-                            local.n_mesh_launches++;
-                            local.mesh_rays += mesh_counts[k];
-                            if (walked[k] == 2) local.mesh_one_rays += mesh_counts[k];
-                        }
-                        local.mesh_records += mesh_counts[k];
                     }
                     if (tail_at >= 0) {
                         HIP_TRY(hipEventElapsedTime(&ms_k, s->evp[1 + 4 * tail_at], s->evp[2 + 4 * tail_at]));
@@ -768,7 +794,10 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
             ++done;
             if (per_stratum) {
                 int stop = per_stratum(user, done, strata);
-                if (stop < 0) return stop;
+                if (stop < 0) {
+                    (void)hipStreamSynchronize(st); // nothing stays queued behind a failed call
+                    return stop;
+                }
                 if (stop > 0) goto finished;
             }
         }
@@ -828,7 +857,16 @@ extern "C" int rt_render_device_noalloc(rt_scene *scene, const rt_options *opts,
         rt_host::set_last_error("rt_render_device_noalloc: no static scratch buffer on this device");
         return RT_ERR_DEVICE;
     }
-    return render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, nullptr, nullptr, &w);
+    // every call on a GPU works in that GPU's one array: a second call while one is running is refused instead of
+    // left to race with it
+    std::atomic<int> &busy = g_noalloc_busy[scene->device];
+    if (busy.exchange(1) != 0) {
+        rt_host::set_last_error("rt_render_device_noalloc: another call is using this GPU's static scratch buffer (calls on one GPU must not overlap)");
+        return RT_ERR_INVALID;
+    }
+    const int rc = render_strata(scene, opts, d_rgb_sum, d_primary_ids, stats, (hipStream_t)stream, nullptr, nullptr, &w);
+    busy.store(0);
+    return rc;
 }
 
 extern "C" int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, const double *d_shard_rgb,
@@ -1001,11 +1039,117 @@ extern "C" int rt_render(rt_scene *scene, const rt_options *opts_in, double *rgb
     return rc;
 }
 
+// system::render + write_render_result_to_file's pixel math (main.rs:106, 201-222) for a caller that wants the
+// image, not the sums: the frame is tone-mapped where it lies and 3 bytes per pixel cross PCIe instead of 24.
+extern "C" int rt_render_rgb8(rt_scene *scene, const rt_options *opts_in, uint8_t *rgb8, int32_t *primary_ids, rt_stats *stats,
+                              const rt_progress *progress)
+{
+    int rc = check_options(opts_in);
+    if (rc) return rc;
+    if (!scene || !rgb8) {
+        rt_host::set_last_error("rt_render_rgb8: null scene or output");
+        return RT_ERR_INVALID;
+    }
+    rt_options opts = *opts_in; // a whole image on this GPU
+    opts.shard_rank = 0;
+    opts.shard_count = 1;
+    opts.flags |= RT_FLAG_ROW_MAJOR;
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t n = (size_t)opts.width * opts.height;
+    if ((rc = ensure_outputs(scene, n, primary_ids != nullptr))) return rc;
+    if ((rc = ensure_snapshot(scene, n))) return rc;
+    rt_stats local;
+    std::memset(&local, 0, sizeof(local));
+    const bool with_progress = progress && (progress->on_stratum || progress->on_snapshot);
+    ProgressCtx ctx{progress, scene, scene->out_rgb, n, nullptr, std::chrono::steady_clock::now()};
+    rc = render_strata(scene, &opts, scene->out_rgb, primary_ids ? scene->out_ids : nullptr, &local, nullptr,
+                       with_progress ? progress_stratum : nullptr, &ctx);
+    if (rc != RT_OK) return rc;
+    if ((rc = rt_tonemap_device(scene->out_rgb, n, (double)local.strata + 1.0, scene->snap_d, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(rgb8, scene->snap_d, n * 3, hipMemcpyDeviceToHost));
+    if (primary_ids) HIP_TRY(hipMemcpy(primary_ids, scene->out_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (stats) *stats = local;
+    return RT_OK;
+}
+
+// Page-locked host memory for the outputs of rt_render / rt_render_rgb8 / rt_render_multi: the copy out of the GPU
+// then runs at the link's speed (58 GB/s measured) instead of through a staging buffer.
+extern "C" int rt_pinned_alloc(size_t bytes, void **out)
+{
+    if (!out) {
+        rt_host::set_last_error("rt_pinned_alloc: null argument");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RT_OK;
+}
+
+extern "C" void rt_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 // ---- one frame over several GPUs of this process ---------------------------------------------------------
 // The reference's one parallel step spreads strata over threads and merges under a mutex (system.rs:288-299);
 // here tile shards are spread over GPUs (pixels are independent, system.rs:244-253) and the finished tiles are
-// gathered to the first scene's GPU over xGMI (hipMemcpyPeerAsync: every peer pushes over its own link), where
-// k_unshard scatters them into the row-major image.  One host thread per GPU drives that GPU's wavefront loop.
+// gathered to the first scene's GPU over xGMI: every peer pushes its shard with hipMemcpyPeerAsync on ITS OWN
+// stream into ITS OWN region of the root's buffer, so the copies run over the peers' links at the same time; the
+// root waits for the peers' events and one k_unshard_all launch scatters all regions into the row-major image.
+// One host thread per GPU drives that GPU's wavefront loop; threads, streams and events stay with the scenes
+// between calls (SceneWorker).
+SceneWorker::~SceneWorker()
+{
+    {
+        std::lock_guard<std::mutex> lock(m);
+        quit = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+}
+
+void SceneWorker::submit(std::function<void()> f)
+{
+    std::unique_lock<std::mutex> lock(m);
+    if (!th.joinable()) th = std::thread([this] { loop(); });
+    job = std::move(f);
+    pending = true;
+    finished = false;
+    cv.notify_all();
+}
+
+void SceneWorker::wait()
+{
+    std::unique_lock<std::mutex> lock(m);
+    cv.wait(lock, [&] { return finished; });
+}
+
+void SceneWorker::loop()
+{
+    std::unique_lock<std::mutex> lock(m);
+    for (;;) {
+        cv.wait(lock, [&] { return pending || quit; });
+        if (quit) return;
+        pending = false;
+        std::function<void()> f = std::move(job);
+        lock.unlock();
+        f();
+        lock.lock();
+        finished = true;
+        cv.notify_all();
+    }
+}
+
+// stream, event and worker thread a scene keeps for rt_render_multi (made on first use, with its device current)
+static int ensure_multi_side(rt_scene *s)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->multi_stream) HIP_TRY(hipStreamCreateWithFlags(&s->multi_stream, hipStreamNonBlocking));
+    if (!s->multi_done) HIP_TRY(hipEventCreateWithFlags(&s->multi_done, hipEventDisableTiming));
+    if (!s->worker) s->worker = new SceneWorker();
+    return RT_OK;
+}
+
 namespace {
 struct MultiBarrier { // all device threads meet between strata when progress is reported
     std::mutex m;
@@ -1045,6 +1189,21 @@ struct MultiShared {
     std::vector<uint8_t> image;           // row-major RGB8 snapshot
     std::vector<std::vector<uint32_t>> maps; // per shard: slot -> pixel
     std::vector<std::string> messages;
+    std::vector<int> rcs;
+    std::mutex fail_mutex;
+    // a device's failure: its code and message stay, everybody else stops at the next stratum
+    void fail(uint32_t k, int code, const std::string &msg)
+    {
+        {
+            std::lock_guard<std::mutex> lock(fail_mutex);
+            if (rcs[k] == RT_OK) {
+                rcs[k] = code;
+                messages[k] = msg;
+            }
+        }
+        error.store(1);
+        barrier.abort();
+    }
 };
 
 struct MultiThreadCtx {
@@ -1078,7 +1237,11 @@ int multi_stratum(void *u, uint32_t done, uint32_t total)
     const int flags = sh->stop.load();
     if (flags & 2) {
         rt_scene *s = sh->scenes[c->k];
-        if (c->n_slots && snapshot_to_host(s, c->d_shard, c->n_slots, done, c->st) != RT_OK) sh->error.store(1);
+        if (c->n_slots) {
+            // a snapshot that fails is this device's failure: the call returns its code, not a shortened render
+            const int rc = snapshot_to_host(s, c->d_shard, c->n_slots, done, c->st);
+            if (rc != RT_OK) sh->fail(c->k, rc, std::string("progress snapshot: ") + rt_last_error());
+        }
         if (!sh->error.load()) {
             const std::vector<uint32_t> &map = sh->maps[c->k];
             for (size_t i = 0; i < c->n_slots; ++i)
@@ -1096,20 +1259,30 @@ int multi_stratum(void *u, uint32_t done, uint32_t total)
 }
 } // namespace
 
-extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts_in, double *rgb_sum,
-                               int32_t *primary_ids, rt_stats *stats, const rt_progress *progress)
+// rgb_sum (f64 sums) or rgb8 (tone-mapped by strata + 1, main.rs:201-222): exactly one is non-null
+static int render_multi_impl(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts_in, double *rgb_sum, uint8_t *rgb8,
+                             int32_t *primary_ids, rt_stats *stats, const rt_progress *progress)
 {
     int rc = check_options(opts_in);
     if (rc) return rc;
-    if (!scenes || n_devices == 0 || !rgb_sum) {
+    if (!scenes || n_devices == 0 || (!rgb_sum && !rgb8)) {
         rt_host::set_last_error("rt_render_multi: null scenes or output, or no device");
         return RT_ERR_INVALID;
     }
-    for (uint32_t k = 0; k < n_devices; ++k)
+    for (uint32_t k = 0; k < n_devices; ++k) {
         if (!scenes[k]) {
             rt_host::set_last_error("rt_render_multi: null scene");
             return RT_ERR_INVALID;
         }
+        // one scene serves one render at a time (its workspace, pinned words and events): the same GPU may appear
+        // more than once, but through scenes of its own
+        for (uint32_t j = 0; j < k; ++j)
+            if (scenes[j] == scenes[k]) {
+                rt_host::set_last_error("rt_render_multi: scenes[" + std::to_string(j) + "] and scenes[" + std::to_string(k) +
+                                        "] are the same rt_scene; create one scene per entry");
+                return RT_ERR_INVALID;
+            }
+    }
     const bool with_progress = progress && (progress->on_stratum || progress->on_snapshot);
     MultiShared sh;
     sh.progress = with_progress ? progress : nullptr;
@@ -1121,12 +1294,20 @@ extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, cons
     sh.barrier.n = n_devices;
     sh.last = std::chrono::steady_clock::now();
     sh.messages.resize(n_devices);
+    sh.rcs.assign(n_devices, RT_OK);
     const size_t n_px = (size_t)opts_in->width * opts_in->height;
-    std::vector<size_t> n_slots(n_devices);
+    std::vector<size_t> n_slots(n_devices), first_slot(n_devices);
+    size_t total_slots = 0;
     for (uint32_t k = 0; k < n_devices; ++k) {
         rt_options o = sh.opts;
         o.shard_rank = k;
         n_slots[k] = (size_t)rt_shard_pixels(&o);
+        first_slot[k] = total_slots; // regions in rank order: what k_unshard_all assumes
+        total_slots += n_slots[k];
+    }
+    if (total_slots > 0xFFFFFFF0ull) {
+        rt_host::set_last_error("rt_render_multi: image too large");
+        return RT_ERR_INVALID;
     }
     if (with_progress && progress->on_snapshot) {
         sh.image.assign(n_px * 3, 0);
@@ -1138,98 +1319,102 @@ extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, cons
             if (n_slots[k] && (rc = rt_shard_map(&o, sh.maps[k].data()))) return rc;
         }
     }
-    // shard buffers on every device (kept by the scenes), the full image on the first
+    // Buffers (kept by the scenes).  Root: [full image | region of shard 0 | region of shard 1 | ...]; a scene on
+    // the root's GPU renders straight into its region; a scene on another GPU renders into a buffer of its own
+    // and pushes it into its region over its link.
     rt_scene *root = scenes[0];
     for (uint32_t k = 0; k < n_devices; ++k) {
-        HIP_TRY(hipSetDevice(scenes[k]->device));
-        const size_t need = (k == 0 ? n_px : 0) + n_slots[k] + (k == 0 && n_devices > 1 ? *std::max_element(n_slots.begin(), n_slots.end()) : 0);
+        if ((rc = ensure_multi_side(scenes[k]))) return rc;
+        const bool local = scenes[k]->device == root->device;
+        const size_t need = k == 0 ? n_px + total_slots : (local ? 1 : n_slots[k]);
         if ((rc = ensure_outputs(scenes[k], need ? need : 1, primary_ids != nullptr))) return rc;
-        if (scenes[k]->device != root->device) {
+        if (!local) {
+            // the push is issued on the peer's stream into the root's memory
             int can = 0;
-            HIP_TRY(hipDeviceCanAccessPeer(&can, root->device, scenes[k]->device));
+            HIP_TRY(hipDeviceCanAccessPeer(&can, scenes[k]->device, root->device));
             if (can) {
-                HIP_TRY(hipSetDevice(root->device));
-                hipError_t e = hipDeviceEnablePeerAccess(scenes[k]->device, 0);
+                hipError_t e = hipDeviceEnablePeerAccess(root->device, 0); // current device: scenes[k]'s (ensure_multi_side)
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
                 (void)hipGetLastError();
             }
         }
     }
-    // layout of scenes[0]'s buffer: [full image | own shard | staging for a peer's shard]; of the others: [own shard]
-    auto shard_rgb = [&](uint32_t k) { return scenes[k]->out_rgb + (k == 0 ? n_px * 3 : 0); };
-    auto shard_ids = [&](uint32_t k) { return primary_ids ? scenes[k]->out_ids + (k == 0 ? n_px : 0) : (int32_t *)nullptr; };
+    if (rgb8) {
+        HIP_TRY(hipSetDevice(root->device));
+        if ((rc = ensure_snapshot(root, n_px))) return rc;
+    }
+    auto region_rgb = [&](uint32_t k) { return root->out_rgb + (n_px + first_slot[k]) * 3; };
+    auto region_ids = [&](uint32_t k) { return primary_ids ? root->out_ids + n_px + first_slot[k] : (int32_t *)nullptr; };
+    auto is_local = [&](uint32_t k) { return scenes[k]->device == root->device; };
+    auto shard_rgb = [&](uint32_t k) { return is_local(k) ? region_rgb(k) : scenes[k]->out_rgb; };
+    auto shard_ids = [&](uint32_t k) { return !primary_ids ? (int32_t *)nullptr : (is_local(k) ? region_ids(k) : scenes[k]->out_ids); };
     std::vector<rt_stats> st(n_devices);
-    std::vector<int> rcs(n_devices, RT_OK);
-    std::vector<hipStream_t> streams(n_devices, nullptr);
     std::vector<MultiThreadCtx> ctxs(n_devices);
     auto worker = [&](uint32_t k) {
+        rt_scene *s = scenes[k];
         rt_options o = sh.opts;
         o.shard_rank = k;
-        if (hipSetDevice(scenes[k]->device) != hipSuccess || hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) {
-            rcs[k] = RT_ERR_DEVICE;
-            sh.messages[k] = "cannot create a stream";
-            sh.error.store(1);
-            sh.barrier.abort();
-            streams[k] = nullptr;
-        }
-        ctxs[k] = MultiThreadCtx{&sh, k, shard_rgb(k), n_slots[k], streams[k]};
-        if (rcs[k] == RT_OK) {
-            // with progress every thread must pass the same barriers: an empty shard still walks the strata
-            rcs[k] = render_strata(scenes[k], &o, shard_rgb(k), shard_ids(k), &st[k], streams[k], with_progress ? multi_stratum : nullptr,
-                                   &ctxs[k], nullptr, /*call_back_for_empty_shards=*/true);
-            if (rcs[k] != RT_OK) {
-                sh.messages[k] = rt_last_error();
-                sh.error.store(1);
-                sh.barrier.abort();
+        ctxs[k] = MultiThreadCtx{&sh, k, shard_rgb(k), n_slots[k], s->multi_stream};
+        // with progress every thread must pass the same barriers: an empty shard still walks the strata
+        int r = render_strata(s, &o, shard_rgb(k), shard_ids(k), &st[k], s->multi_stream, with_progress ? multi_stratum : nullptr,
+                              &ctxs[k], nullptr, /*call_back_for_empty_shards=*/true);
+        if (r == RT_OK && n_slots[k] && !sh.error.load()) {
+            // the one exchange step, this GPU's half: push the shard into its region of the root's buffer
+            hipError_t e = hipSuccess;
+            if (!is_local(k)) {
+                e = hipMemcpyPeerAsync(region_rgb(k), root->device, s->out_rgb, s->device, n_slots[k] * 3 * sizeof(double), s->multi_stream);
+                if (e == hipSuccess && primary_ids)
+                    e = hipMemcpyPeerAsync(region_ids(k), root->device, s->out_ids, s->device, n_slots[k] * sizeof(int32_t), s->multi_stream);
+            }
+            if (e == hipSuccess) e = hipEventRecord(s->multi_done, s->multi_stream);
+            if (e != hipSuccess) {
+                r = RT_ERR_DEVICE;
+                rt_host::set_last_error(std::string("tile gather: ") + hipGetErrorString(e));
             }
         }
+        if (r != RT_OK) sh.fail(k, r, rt_last_error());
     };
     if (n_devices == 1) {
         worker(0);
     } else {
-        std::vector<std::thread> pool;
-        for (uint32_t k = 0; k < n_devices; ++k) pool.emplace_back(worker, k);
-        for (auto &t : pool) t.join();
+        for (uint32_t k = 1; k < n_devices; ++k) scenes[k]->worker->submit([&worker, k] { worker(k); });
+        worker(0); // the calling thread drives the root's GPU (and talks to the caller's callbacks)
+        for (uint32_t k = 1; k < n_devices; ++k) scenes[k]->worker->wait();
     }
     rc = RT_OK;
     for (uint32_t k = 0; k < n_devices; ++k)
-        if (rcs[k] != RT_OK) {
-            rc = rcs[k];
+        if (sh.rcs[k] != RT_OK && rc == RT_OK) {
+            rc = sh.rcs[k];
             rt_host::set_last_error("rt_render_multi: device " + std::to_string(k) + ": " + sh.messages[k]);
         }
-    if (rc == RT_OK) {
-        // the one exchange step: every shard to the first GPU, scattered into the row-major image there
-        HIP_TRY(hipSetDevice(root->device));
-        hipStream_t s0 = streams[0];
-        double *stage_rgb = root->out_rgb + (n_px + n_slots[0]) * 3;
-        int32_t *stage_ids = primary_ids ? root->out_ids + n_px + n_slots[0] : nullptr;
-        for (uint32_t k = 0; k < n_devices && rc == RT_OK; ++k) {
-            rt_options o = sh.opts;
-            o.shard_rank = k;
-            if (n_slots[k] == 0) continue;
-            const double *src_rgb = shard_rgb(k);
-            const int32_t *src_ids = shard_ids(k);
-            if (k != 0) {
-                HIP_TRY(hipMemcpyPeerAsync(stage_rgb, root->device, src_rgb, scenes[k]->device, n_slots[k] * 3 * sizeof(double), s0));
-                if (primary_ids)
-                    HIP_TRY(hipMemcpyPeerAsync(stage_ids, root->device, src_ids, scenes[k]->device, n_slots[k] * sizeof(int32_t), s0));
-                src_rgb = stage_rgb;
-                src_ids = stage_ids;
-            }
-            rc = rt_unshard_device(&o, k, src_rgb, root->out_rgb, src_ids, primary_ids ? root->out_ids : nullptr, s0);
-        }
-        if (rc == RT_OK) {
-            HIP_TRY(hipMemcpyAsync(rgb_sum, root->out_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost, s0));
-            if (primary_ids) HIP_TRY(hipMemcpyAsync(primary_ids, root->out_ids, n_px * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
-            HIP_TRY(hipStreamSynchronize(s0));
-        }
+    if (rc != RT_OK) {
+        // leave nothing queued behind a failed call
+        for (uint32_t k = 0; k < n_devices; ++k)
+            if (hipSetDevice(scenes[k]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[k]->multi_stream);
+        return rc;
     }
-    for (uint32_t k = 0; k < n_devices; ++k)
-        if (streams[k]) {
-            (void)hipSetDevice(scenes[k]->device);
-            (void)hipStreamDestroy(streams[k]);
+    {
+        HIP_TRY(hipSetDevice(root->device));
+        hipStream_t s0 = root->multi_stream;
+        for (uint32_t k = 1; k < n_devices; ++k)
+            if (n_slots[k]) HIP_TRY(hipStreamWaitEvent(s0, scenes[k]->multi_done, 0));
+        const rt_shard_geom g = rt_shard_geom_make(sh.opts.width, sh.opts.height, sh.opts.tile_size, n_devices);
+        hipLaunchKernelGGL(k_unshard_all, dim3((uint32_t)((total_slots + 255) / 256)), dim3(256), 0, s0, g, (uint32_t)total_slots,
+                           root->out_rgb + n_px * 3, root->out_rgb, primary_ids ? root->out_ids + n_px : nullptr,
+                           primary_ids ? root->out_ids : nullptr);
+        HIP_TRY(hipGetLastError());
+        uint32_t strata_done = 0;
+        for (uint32_t k = 0; k < n_devices; ++k) strata_done = std::max(strata_done, st[k].strata);
+        if (rgb8) {
+            if ((rc = rt_tonemap_device(root->out_rgb, n_px, (double)strata_done + 1.0, root->snap_d, s0))) return rc;
+            HIP_TRY(hipMemcpyAsync(rgb8, root->snap_d, n_px * 3, hipMemcpyDeviceToHost, s0));
+        } else {
+            HIP_TRY(hipMemcpyAsync(rgb_sum, root->out_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost, s0));
         }
-    if (stats && rc == RT_OK) {
+        if (primary_ids) HIP_TRY(hipMemcpyAsync(primary_ids, root->out_ids, n_px * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        HIP_TRY(hipStreamSynchronize(s0));
+    }
+    if (stats) {
         *stats = st[0];
         for (uint32_t k = 1; k < n_devices; ++k) {
             stats->rays += st[k].rays;
@@ -1245,7 +1430,27 @@ extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, cons
             if (st[k].ms_device > stats->ms_device) stats->ms_device = st[k].ms_device; // the slowest device
         }
     }
-    return rc;
+    return RT_OK;
+}
+
+extern "C" int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts_in, double *rgb_sum,
+                               int32_t *primary_ids, rt_stats *stats, const rt_progress *progress)
+{
+    if (!rgb_sum) {
+        rt_host::set_last_error("rt_render_multi: null output");
+        return RT_ERR_INVALID;
+    }
+    return render_multi_impl(scenes, n_devices, opts_in, rgb_sum, nullptr, primary_ids, stats, progress);
+}
+
+extern "C" int rt_render_multi_rgb8(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts_in, uint8_t *rgb8,
+                                    int32_t *primary_ids, rt_stats *stats, const rt_progress *progress)
+{
+    if (!rgb8) {
+        rt_host::set_last_error("rt_render_multi_rgb8: null output");
+        return RT_ERR_INVALID;
+    }
+    return render_multi_impl(scenes, n_devices, opts_in, nullptr, rgb8, primary_ids, stats, progress);
 }
 
 extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const double *origins, const double *directions,
@@ -1272,17 +1477,21 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     int rc = ensure_workspace(s, (size_t)n, 1);
     if (rc) return rc;
     const Workspace &w = s->own;
-    // de-interleave on the host into the SoA queue
-    std::vector<double> col(n);
-    for (int c = 0; c < 3; ++c) {
-        for (uint64_t i = 0; i < n; ++i) col[i] = origins[3 * i + c];
-        HIP_TRY(hipMemcpy(w.q[0].o[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
-        for (uint64_t i = 0; i < n; ++i) col[i] = directions[3 * i + c];
-        HIP_TRY(hipMemcpy(w.q[0].d[c], col.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    // The caller's interleaved rays go up in two copies and are de-interleaved on the device; the hits come back
+    // interleaved in one.  Staging lives in arrays of the workspace this call does not use otherwise - the
+    // attenuation arrays of the second ray queue and of the mesh queue (three consecutive arrays each, see
+    // carve_workspace) going up, the first ray queue's nine arrays, free again after the trace, coming back.
+    double *stage_o = w.q[1].thr[0], *stage_d = w.mq.thr[0];
+    rt_hit *stage_hits = reinterpret_cast<rt_hit *>(w.q[0].o[0]);
+    if ((size_t)(w.q[1].thr[2] - w.q[1].thr[0]) < 2 * (size_t)n || (size_t)(w.mq.thr[2] - w.mq.thr[0]) < 2 * (size_t)n ||
+        (size_t)(w.q[0].thr[2] - w.q[0].o[0]) < 8 * (size_t)n || sizeof(rt_hit) != 7 * sizeof(double)) {
+        rt_host::set_last_error("rt_trace_rays: workspace layout does not hold the staging arrays");
+        return RT_ERR_DEVICE;
     }
+    HIP_TRY(hipMemcpy(stage_o, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(stage_d, directions, n * 3 * sizeof(double), hipMemcpyHostToDevice));
     uint32_t n32 = (uint32_t)n;
-    hipLaunchKernelGGL(k_iota, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, w.q[0].slot, w.q[0].pixel,
-                       w.q[0].thr[0], w.q[0].thr[1], w.q[0].thr[2]);
+    hipLaunchKernelGGL(k_rays_in, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, stage_o, stage_d, w.q[0]);
     HIP_TRY(hipMemcpy(w.d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(w.d_guards, 0, 8 * sizeof(uint32_t)));
     PassParams pp;
@@ -1306,24 +1515,9 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
                            nullptr, hit, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<int32_t> obj(n);
-    std::vector<double> cols[6];
-    double *src[6] = {hit.t, hit.n[0], hit.n[1], hit.n[2], hit.uv[0], hit.uv[1]};
-    for (int c = 0; c < 6; ++c) {
-        cols[c].resize(n);
-        HIP_TRY(hipMemcpy(cols[c].data(), src[c], n * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    HIP_TRY(hipMemcpy(obj.data(), hit.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) {
-        hits[i].t = cols[0][i];
-        hits[i].n[0] = cols[1][i];
-        hits[i].n[1] = cols[2][i];
-        hits[i].n[2] = cols[3][i];
-        hits[i].uv[0] = cols[4][i];
-        hits[i].uv[1] = cols[5][i];
-        hits[i].object = obj[i];
-        hits[i].pad = 0;
-    }
+    hipLaunchKernelGGL(k_hits_out, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, hit, stage_hits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hits, stage_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         uint32_t g[6];

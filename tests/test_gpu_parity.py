@@ -734,6 +734,19 @@ def test_render_multi_equals_whole_and_reports_progress(rt, tmp_path):
         rgb, ids, st = rt.render_multi(o, devs[:n])
         assert np.array_equal(rgb, whole) and np.array_equal(ids, wids), n
         assert st.rays == wst.rays and st.strata == 9 and st.primary_rays == wst.primary_rays
+    # the same frame as an image: tone-mapped on the first GPU by strata + 1 (main.rs:201-222), 3 bytes per pixel out
+    img8, ids8, st8 = rt.render_multi(o, devs[:3], rgb8=True)
+    assert np.array_equal(img8, rt.tonemap(whole, 10)) and np.array_equal(ids8, wids) and st8.rays == wst.rays
+    one8, oid8, ost8 = devs[0].render_rgb8(o, want_ids=True)
+    assert np.array_equal(one8, img8) and np.array_equal(oid8, wids) and ost8.rays == wst.rays
+    # page-locked buffers the DeviceScene keeps: the same frame, the same arrays handed out again
+    r1, i1, _ = devs[0].render(o, reuse=True)
+    assert np.array_equal(r1, whole) and np.array_equal(i1, wids)
+    r2, _, _ = devs[0].render(rt.Options(width=300, height=200, samples=9, seed=5, tile_size=32), reuse=True)
+    assert r2 is r1 and not np.array_equal(r2, whole)
+    # one scene serves one render at a time: the same rt_scene twice is refused
+    with pytest.raises(RuntimeError, match="same rt_scene"):
+        rt.render_multi(o, [devs[0], devs[1], devs[0]])
     # more shards than tiles: some devices own nothing
     small = rt.Options(width=40, height=30, samples=4, seed=4, tile_size=32)
     ssc = rt.parse_file(small, parity.scene_path("meshes2"), parity.ASSETS)

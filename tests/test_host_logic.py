@@ -98,6 +98,26 @@ def test_layout_contract_ctypes_rust_and_docs():
     assert layout_table.table(lay) in doc, "INTEGRATION.md's layout table is stale: python tools/layout_table.py"
 
 
+def test_build_recipes_list_every_source():
+    """ffi/build.rs (never compiled here: no Rust toolchain) must rebuild on exactly the files raytracer_amd/build.py
+    builds from, and both lists must hold every file under csrc/ - a device header missing from either would leave a
+    stale library behind an edit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_build_recipe", os.path.join(ROOT, "raytracer_amd", "build.py"))
+    recipe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(recipe)
+    with open(os.path.join(ROOT, "ffi", "build.rs")) as f:
+        rs = f.read()
+    rs_sources = re.findall(r'\("([\w.]+)", "(?:hip|c\+\+)"\)', rs)
+    block = re.search(r"for header in \[(.*?)\]", rs, re.S).group(1)
+    rs_headers = re.findall(r'"([^"]+)"', block)
+    assert sorted(rs_sources) == sorted(recipe.SOURCES)
+    assert sorted(rs_headers) == sorted(recipe.HEADERS), set(rs_headers) ^ set(recipe.HEADERS)
+    on_disk = {n for n in os.listdir(os.path.join(ROOT, "raytracer_amd", "csrc")) if n.endswith((".h", ".hip", ".cpp", ".inc"))}
+    listed = set(recipe.SOURCES) | {h for h in recipe.HEADERS if not h.startswith("../")}
+    assert on_disk == listed, on_disk ^ listed
+
+
 # SURVEY appendix A: objects per scene, in file order
 EXPECTED_OBJECTS = {"three-spheres": 11, "cornell_box": 8, "mesh": 3, "torus": 3, "csg": 3, "cylinder": 4,
                     "transformations": 3, "room": 5, "fog_light": 5}

@@ -1,6 +1,7 @@
 """rt_render_device_noalloc: the allocation-free variant of rt_render_device (wavefront state in a static
 device array of the library).  Same outputs, bit for bit, on two calls in a row, the second smaller (the
-array keeps the first call's contents); sizes beyond the array are refused."""
+array keeps the first call's contents); sizes beyond the array are refused; the call leaves the device's free
+memory as it found it; calls that overlap on the GPU are refused, not left to race."""
 import ctypes as C
 
 import numpy as np
@@ -20,9 +21,13 @@ def _shard(rt, dev, o, noalloc, rank=0, count=1):
     oc = o.to_c(rank, count)
     st = _capi.rt_stats()
     fn = rt.lib.rt_render_device_noalloc if noalloc else rt.lib.rt_render_device
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]  # hipMemGetInfo: the device's free bytes, whoever allocates
     rc = fn(dev._h, C.byref(oc), C.c_void_p(buf.data_ptr()), C.c_void_p(ids.data_ptr()), C.byref(st),
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
+    if noalloc:
+        assert torch.cuda.mem_get_info()[0] == free_before, "rt_render_device_noalloc changed the device's free memory"
     return rc, buf.cpu().numpy(), ids.cpu().numpy(), st
 
 
@@ -50,3 +55,45 @@ def test_noalloc_equals_render_device(rt):
     o = rt.Options(width=64, height=64, samples=1, seed=1, max_depth=_capi.RT_NOALLOC_MAX_DEPTH + 1)
     rc, rgb, ids, st = _shard(rt, scenes["mesh"], o, True)
     assert rc == _capi.RT_ERR_UNSUPPORTED
+
+
+def test_noalloc_overlapping_calls_are_refused_not_raced(rt):
+    """Two host threads call the entry point on the same GPU at once (ctypes releases the GIL for the call): every
+    call either renders the right frame or is refused with RT_ERR_INVALID - the shared array is never worked on by
+    two calls."""
+    import threading
+    from raytracer_amd import _capi
+    o = rt.Options(width=320, height=240, samples=1, seed=3)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    devs = [rt.DeviceScene(sc), rt.DeviceScene(sc)]
+    rc, want, _, _ = _shard(rt, devs[0], o, False)
+    assert rc == 0
+    import torch
+    n = want.size // 3
+    results = [[], []]
+
+    def worker(k):
+        stream = torch.cuda.Stream()
+        buf = torch.zeros(n * 3, dtype=torch.float64, device="cuda")
+        oc = o.to_c(0, 1)
+        for _ in range(12):
+            st = _capi.rt_stats()
+            rc = rt.lib.rt_render_device_noalloc(devs[k]._h, C.byref(oc), C.c_void_p(buf.data_ptr()), None, C.byref(st),
+                                                 C.c_void_p(stream.cuda_stream))
+            msg = rt.lib.rt_last_error() if rc else b""
+            stream.synchronize()
+            results[k].append((rc, msg, buf.cpu().numpy().copy() if rc == 0 else None))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    done = 0
+    for rc, msg, img in results[0] + results[1]:
+        if rc == 0:
+            assert np.array_equal(img, want)
+            done += 1
+        else:
+            assert rc == _capi.RT_ERR_INVALID and b"another call" in msg, (rc, msg)
+    assert done >= 12  # whoever was not refused rendered correctly; a thread alone on the GPU is never refused
