@@ -55,6 +55,7 @@ void set_last_error(const std::string &msg);
 #include "rt_k_mesh.h"
 #include "rt_k_mesh_pool.h"
 #include "rt_k_shade.h"
+#include "rt_k_tail.h"
 
 // =====================================================================================
 // host side
@@ -139,6 +140,13 @@ struct rt_scene {
     bool any_grid = false, any_kd = false; // (object, mesh) jobs walked through grids / through kd-trees
     uint32_t mesh_kd_lds_bytes = 0; // dynamic LDS of k_mesh<KD>: job records + stacks
     uint32_t mesh_pool_lds_bytes = 0; // dynamic LDS of k_mesh_one (tables + the waves' stacks); 0: several jobs or no room, k_mesh walks the grids
+    uint32_t tail_grid_lds_bytes = 0; // dynamic LDS of k_tail_grid (scene tables + the one job's grid tables); 0: k_tail takes the tail
+    // What the last stratum of the same shape did (pass_hint_key: image, tiles, shard, max_depth): rays per depth level
+    // and where the tail took over.  With it the next stratum's passes are queued without waiting for a single
+    // queue length to come back - the lengths only size grids, the kernels read the true ones on the device.
+    uint64_t pass_hint_key[2] = {0, 0};
+    std::vector<uint32_t> pass_hint_counts; // rays entering depth k (as far as the passes went)
+    int pass_hint_tail_at = -1;             // depth at which the tail kernel took over, -1: it did not
     uint32_t host_depth_cap = 0;  // max_depth the pinned buffer and the events below are sized for
     uint32_t *h_pinned = nullptr; // readback slot
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -375,6 +383,18 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     for (int k = 0; k < 3; ++k) s->dev.background[k] = flat.background[k];
     s->dev.cam_fov_factor = flat.cam_fov_factor;
     std::memcpy(s->dev.cam_c2w, flat.cam_c2w, sizeof(flat.cam_c2w));
+    {
+        // k_tail_grid (one lane per path, the grid walk inside): the same single grid job as k_mesh_one, with the
+        // scene tables in LDS beside the grid tables
+        int lds_limit = 0;
+        if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device) != hipSuccess || lds_limit <= 0)
+            lds_limit = 65536;
+        const uint32_t want = ((scene_lds_bytes(s->dev) + 15u) & ~15u) + s->mesh_lds_bytes;
+        const char *tg_env = getenv("RT_TAIL_GRID"); // "0": k_tail takes every tail (measurements, tests)
+        s->tail_grid_lds_bytes = (s->mesh_pool_lds_bytes != 0u && scene_lds_bytes(s->dev) != 0u && want <= (uint32_t)lds_limit &&
+                                  !(tg_env && !strcmp(tg_env, "0"))) ? want : 0u;
+        RT_TRACE("k_tail_grid LDS: %u bytes", s->tail_grid_lds_bytes);
+    }
     *out = s;
     RT_TRACE("scene created");
     return RT_OK;
@@ -559,17 +579,43 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     return walked;
 }
 
+#ifndef RT_TAIL_FRAC
+#define RT_TAIL_FRAC 24u // k_tail_grid takes over when at most 1 / RT_TAIL_FRAC of the shard's slots still hold a path
+#endif
 #define RT_TAIL_MAX_TESTS 36000000ull // paths x triangles below which k_tail takes the rest of the stratum (measured)
 
 static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q, const PassParams &pp, double *d_rgb)
 {
+    const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
+    uint32_t *lane_totals = w.d_counts + 2 * (pp.max_depth + 2);
+    if (s->tail_grid_lds_bytes != 0u && variant != 8) {
+        // one lane per path, the scene's one mesh through its grid: a workgroup per 256 paths (they are not all
+        // resident at once when many paths are left; the ones that wait start as the short paths' waves finish)
+        uint64_t blocks = ((uint64_t)live + RT_TAILG_LANES - 1) / RT_TAILG_LANES;
+        if (blocks > 65535u * 16u) blocks = 65535u * 16u;
+        if (blocks < 1) blocks = 1;
+#define LAUNCH_TG(C, M, T)                                                                                             \
+    hipLaunchKernelGGL((k_tail_grid<C, M, T>), dim3((uint32_t)blocks), dim3(RT_TAILG_LANES), s->tail_grid_lds_bytes, st, s->dev, q,   \
+                       w.d_counts, d_rgb, pp, w.d_guards, lane_totals)
+        switch (variant) {
+        case 0: LAUNCH_TG(false, false, false); break;
+        case 1: LAUNCH_TG(false, false, true); break;
+        case 2: LAUNCH_TG(false, true, false); break;
+        case 3: LAUNCH_TG(false, true, true); break;
+        case 4: LAUNCH_TG(true, false, false); break;
+        case 5: LAUNCH_TG(true, false, true); break;
+        case 6: LAUNCH_TG(true, true, false); break;
+        default: LAUNCH_TG(true, true, true); break;
+        }
+#undef LAUNCH_TG
+        return;
+    }
     uint64_t blocks = ((uint64_t)live * (s->has_mesh ? 64 : 1) + RT_BLOCK - 1) / RT_BLOCK; // wave or lane per path
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
 #define LAUNCH_T(C, M, T, L)                                                                                           \
     hipLaunchKernelGGL((k_tail<C, M, T, L>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, w.d_counts,       \
-                       w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, w.d_counts + 2 * (pp.max_depth + 2))
-    const int variant = scene_lds_bytes(s->dev) == 0u ? 8 : (s->has_csg ? 4 : 0) | (s->has_medium ? 2 : 0) | (s->has_torus ? 1 : 0);
+                       w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
     switch (variant) {
     case 0: LAUNCH_T(false, false, false, true); break;
     case 1: LAUNCH_T(false, false, true, true); break;
@@ -676,15 +722,33 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 // back (counts never grow).  The kernels read the true count on the device; the bound
                 // only sizes grids and picks between k_mesh and k_mesh_brute.
                 uint32_t live = n_slots;
-                // paths left at which the tail kernel takes over (one wave per path, meshes by brute force)
-                static const uint32_t tail_env = getenv("RT_TAIL_MAX") ? (uint32_t)atoi(getenv("RT_TAIL_MAX")) : 0xFFFFFFFFu;
+                // Paths left at which one launch takes the rest of the stratum.  k_tail_grid (one lane per path, the
+                // mesh through its grid): a fraction of the shard's slots - the passes below that have a floor of
+                // ~0.1 ms each whatever they hold.  k_tail: one wave per path with the triangles by brute force,
+                // or one lane per path in a scene without meshes.
+                const uint32_t tail_env = getenv("RT_TAIL_MAX") ? (uint32_t)atoi(getenv("RT_TAIL_MAX")) : 0xFFFFFFFFu;
+                const uint32_t tail_frac = getenv("RT_TAIL_FRAC") ? (uint32_t)std::max(1, atoi(getenv("RT_TAIL_FRAC"))) : RT_TAIL_FRAC;
                 uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 16384u;
                 if (tail_max > 16384u) tail_max = 16384u;
+                if (s->tail_grid_lds_bytes != 0u && n_slots / tail_frac > tail_max) tail_max = n_slots / tail_frac;
                 if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
-                static const uint32_t run_ahead = getenv("RT_RUN_AHEAD") ? (uint32_t)atoi(getenv("RT_RUN_AHEAD")) : 2u;
+                const uint32_t run_ahead = getenv("RT_RUN_AHEAD") ? (uint32_t)atoi(getenv("RT_RUN_AHEAD")) : 2u;
+                // What the last stratum of this shape did: its passes are queued again without a single wait
+                // (RT_PASS_HINT=0: always follow the counts).
+                const bool hint_env = !(getenv("RT_PASS_HINT") && !strcmp(getenv("RT_PASS_HINT"), "0"));
+                const uint64_t hint_key[2] = {((uint64_t)opts->width << 32) | opts->height,
+                                              ((uint64_t)g.tile << 48) | ((uint64_t)(rank & 0xFFFFu) << 32) | ((uint64_t)(g.shard_count & 0xFFFFu) << 16) | (opts->max_depth & 0xFFFFu)};
+                const bool hinted = hint_env && run_ahead != 0u && !s->pass_hint_counts.empty() && s->pass_hint_key[0] == hint_key[0] &&
+                                    s->pass_hint_key[1] == hint_key[1];
+                // bound on the rays entering depth k, from the hint (a margin: seeds differ from frame to frame)
+                auto hint_bound = [&](uint32_t k) {
+                    const uint64_t c = k < s->pass_hint_counts.size() ? s->pass_hint_counts[k] : 0u;
+                    const uint64_t b = c + c / 8u + 1024u;
+                    return (uint32_t)std::min<uint64_t>(b, n_slots);
+                };
                 int cur = 0;
                 uint32_t passes = 0;
-                int tail_at = -1; // depth at which k_tail took over
+                int tail_at = -1; // depth at which the tail kernel took over
                 uint8_t *walked = s->walked.data(); // sized by ensure_host_side
                 std::memset(walked, 0, opts->max_depth + 1);
                 for (uint32_t depth = 0; depth < opts->max_depth; ++depth) {
@@ -700,6 +764,20 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     STAGE_EV(hipEventRecord(s->evp[4 + 4 * depth], st));
                     ++passes;
                     cur = 1 - cur;
+                    // inside the hinted prefix: the next pass (or the tail) is queued at once
+                    if (hinted && depth + 1 < opts->max_depth &&
+                        ((int)depth + 1 == s->pass_hint_tail_at || depth + 1 < (uint32_t)s->pass_hint_counts.size())) {
+                        live = hint_bound(depth + 1);
+                        if ((int)depth + 1 == s->pass_hint_tail_at) {
+                            pp.depth = depth + 1;
+                            STAGE_EV(hipEventRecord(s->evp[1 + 4 * (depth + 1)], st));
+                            launch_tail(s, w, st, live, w.q[cur], pp, d_rgb);
+                            STAGE_EV(hipEventRecord(s->evp[2 + 4 * (depth + 1)], st));
+                            tail_at = (int)depth + 1;
+                            break;
+                        }
+                        continue;
+                    }
                     // queue length of the next pass: copied back asynchronously after every pass.  The
                     // host waits for the copy of two passes ago only, so the device always has work
                     // queued across the copy's round trip; near the tail threshold (and on the last
@@ -707,7 +785,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     uint32_t *h_live = s->h_pinned + 2 * (opts->max_depth + 2) + 8;
                     HIP_TRY(hipMemcpyAsync(h_live + depth + 1, w.d_counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipEventRecord(s->evr[depth + 1], st));
-                    const bool exact = live <= 8u * tail_max || depth + 1 == opts->max_depth || run_ahead == 0u;
+                    const bool exact = live <= 8u * tail_max || depth + 1 == opts->max_depth || run_ahead == 0u || hinted;
                     int known = exact ? (int)depth + 1 : (int)depth + 1 - (int)run_ahead;
                     if (known >= 1) HIP_TRY(hipEventSynchronize(s->evr[known]));
                     for (int k = (int)depth + 1; k > known && k >= 1; --k)
@@ -732,6 +810,31 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                                        hipMemcpyDeviceToHost, st)); // rays per depth, mesh-queue lengths per depth, lane totals
                 HIP_TRY(hipStreamSynchronize(st));
                 const uint32_t *mesh_counts = s->h_pinned + (opts->max_depth + 2);
+                {
+                    // the hint for the next stratum of this shape: the counts as far as the passes went, and the
+                    // first level whose count is under the tail's threshold (one level later than this time when
+                    // the tail took over above it: the levels below were not counted)
+                    const uint32_t known_levels = tail_at >= 0 ? (uint32_t)tail_at + 1u : std::min(passes + 1u, opts->max_depth);
+                    s->pass_hint_counts.assign(s->h_pinned, s->h_pinned + known_levels);
+                    s->pass_hint_counts[0] = n_slots;
+                    int next_tail = -1;
+                    for (uint32_t k = 1; k < known_levels && k < opts->max_depth; ++k)
+                        if (s->pass_hint_counts[k] <= tail_max) {
+                            next_tail = s->pass_hint_counts[k] ? (int)k : -1; // nothing left there: the passes simply end
+                            if (!s->pass_hint_counts[k]) s->pass_hint_counts.resize(k);
+                            break;
+                        }
+                    if (next_tail < 0 && tail_at >= 0 && (uint32_t)tail_at + 1u < opts->max_depth && s->pass_hint_counts.size() == known_levels) {
+                        next_tail = tail_at + 1;
+                        s->pass_hint_counts.push_back(s->pass_hint_counts[tail_at]); // a bound
+                    }
+                    if (next_tail >= 0) s->pass_hint_counts.resize((size_t)next_tail + 1);
+                    s->pass_hint_tail_at = next_tail;
+                    s->pass_hint_key[0] = hint_key[0];
+                    s->pass_hint_key[1] = hint_key[1];
+                    RT_TRACE("hint: %zu levels, tail at %d (this stratum: %u passes, tail at %d, %s)", s->pass_hint_counts.size(),
+                             next_tail, passes, tail_at, hinted ? "hinted" : "followed the counts");
+                }
                 if (rt_debug())
                     for (uint32_t k = 0; k < passes; ++k)
                         RT_TRACE("pass %u: rays %u mesh queue %u", k, s->h_pinned[k], mesh_counts[k]);
@@ -817,6 +920,26 @@ finished:
     for (int k = 0; k < 5; ++k) local.guards[k] = s->h_pinned[k];
     local.interval_overflow = s->h_pinned[5];
     local.strata = n_slots ? done : strata; // fewer than floor(sqrt(samples))^2 when the callback stopped the render
+#ifdef RT_TAILG_PROF
+    {
+        unsigned long long mx[64][4], sm[64][8];
+        (void)hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_tg_max), sizeof(mx));
+        (void)hipMemcpyFromSymbol(sm, HIP_SYMBOL(g_tg_sum), sizeof(sm));
+        double tot = 0.0;
+        for (int l = 0; l < 64 && sm[l][4]; ++l) {
+            const double w_ = (double)sm[l][4];
+            fprintf(stderr, "[k_tail_grid] level +%2d: waves %6llu lanes/wave %5.1f wanting %5.1f | slowest wave us: isect %6.2f grid %6.2f wave-brute %6.2f shade %6.2f | mean us: %5.2f %5.2f %5.2f %5.2f\n",
+                    l, sm[l][4], sm[l][5] / w_, sm[l][6] / w_, mx[l][0] / 100.0, mx[l][1] / 100.0, mx[l][2] / 100.0, mx[l][3] / 100.0,
+                    sm[l][0] / w_ / 100.0, sm[l][1] / w_ / 100.0, sm[l][2] / w_ / 100.0, sm[l][3] / w_ / 100.0);
+            tot += (mx[l][0] + mx[l][1] + mx[l][2] + mx[l][3]) / 100.0;
+        }
+        fprintf(stderr, "[k_tail_grid] sum of the slowest phases: %.1f us\n", tot);
+        std::memset(mx, 0, sizeof(mx));
+        std::memset(sm, 0, sizeof(sm));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tg_max), mx, sizeof(mx));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tg_sum), sm, sizeof(sm));
+    }
+#endif
 #ifdef RT_MESH_PROF
     {
         unsigned long long pf[14];

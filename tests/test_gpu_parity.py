@@ -939,3 +939,43 @@ def test_stats_name_the_mesh_kernel(rt, monkeypatch):
     off = rt.DeviceScene(rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS))
     _, _, st3 = off.render(o)
     assert st3.mesh_rays == st.mesh_rays and st3.mesh_one_rays == 0 and st3.rays == st.rays
+
+
+def test_tail_takeover_is_invisible(rt, monkeypatch):
+    """Where the per-depth passes hand over to the one-launch tail changes nothing: k_tail_grid (one lane per path,
+    grid walk or the wave on one ray) taking over after the first pass, at its default threshold, or never (all
+    passes), and k_tail (RT_TAIL_GRID=0, one wave per path) give the same frame bit for bit and the same ray count;
+    so does a second render of the same shape, whose passes are queued from the first one's counts without waiting
+    for a queue length (the pass hint), and one with the hint switched off."""
+    o = rt.Options(width=640, height=360, samples=1, seed=11)
+    sc = rt.parse_file(o, parity.scene_path("mesh"), parity.ASSETS)
+    monkeypatch.setenv("RT_TAIL_MAX", "0")  # no tail: every level is a pass
+    dev = rt.DeviceScene(sc)
+    want, wids, wst = dev.render(o)
+    assert wst.bounce_passes > 8
+    for tail_max, hint in (("100000000", "1"), ("100000000", "1"), ("3000", "0"), (None, "1"), (None, "1"), (None, "0")):
+        if tail_max is None:
+            monkeypatch.delenv("RT_TAIL_MAX", raising=False)
+        else:
+            monkeypatch.setenv("RT_TAIL_MAX", tail_max)
+        monkeypatch.setenv("RT_PASS_HINT", hint)
+        rgb, ids, st = dev.render(o)
+        assert np.array_equal(rgb, want) and np.array_equal(ids, wids), (tail_max, hint)
+        assert st.rays == wst.rays and st.bounce_passes == wst.bounce_passes, (tail_max, hint)
+    # another seed through the hinted passes: equal to a scene that follows the counts and uses k_tail
+    o2 = rt.Options(width=640, height=360, samples=4, seed=12)
+    rgb2, ids2, st2 = dev.render(o2)
+    monkeypatch.setenv("RT_TAIL_GRID", "0")
+    monkeypatch.setenv("RT_PASS_HINT", "0")
+    old = rt.DeviceScene(sc)
+    rgb3, ids3, st3 = old.render(o2)
+    assert np.array_equal(rgb2, rgb3) and np.array_equal(ids2, ids3) and st2.rays == st3.rays
+    # a transformed mesh object (rotation + non-uniform scale: the job's maps are not the identity)
+    text = open(parity.scene_path("mesh")).read().replace("translate <0, 1, 0>", "rotate_x 20 rotate_y 30 scale <1.2, 0.8, 1> translate <0, 1, 0>")
+    assert "rotate_x 20" in text
+    sc4 = rt.parse(o, text, parity.ASSETS)
+    r4, i4, s4 = old.__class__(sc4).render(o)
+    monkeypatch.delenv("RT_TAIL_GRID")
+    monkeypatch.setenv("RT_TAIL_MAX", "100000000")
+    r5, i5, s5 = rt.DeviceScene(sc4).render(o)
+    assert np.array_equal(r4, r5) and np.array_equal(i4, i5) and s4.rays == s5.rays

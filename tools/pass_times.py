@@ -12,7 +12,7 @@ for r in frame:
     name = r["Kernel_Name"].replace("void ", "").split("<")[0].split("(")[0]
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     line.append("%s %.0f" % (name, us))
-    if name in ("k_shade", "k_tail"):
+    if name in ("k_shade", "k_tail", "k_tail_grid"):
         print("  ".join(line))
         line = []
 if line:
