@@ -45,6 +45,7 @@ BYTES_PER_RAY_MESH = 48 + 12 + 52   # k_mesh: mesh record by position (origin + 
 BYTES_PER_RAY_MESH_ONE = 48 + 12 + 12  # k_mesh_one: the same read; t and triangle written (k_shade merges them into the hit)
 BYTES_PER_RAY_SHADE = 132 + 80      # mesh record (ray + hit) read, scattered ray written (or 24 B of frame buffer updated)
 BYTES_PER_RAY_SHADE_ONE = 132 + 12 + 80  # after k_mesh_one: its t and triangle read as well
+BYTES_PER_RAY_TAIL = 80 + 24          # the one-launch tail: a path record read when it takes over; 24 B of frame buffer when the path ends (per segment: an upper bound)
 BYTES_PER_RAY_FRAME = 2 * 80 + 2 * 52
 BYTES_PER_PIXEL_SAMPLE = 24
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -246,12 +247,6 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rays = sum(st.rays for st in stats)
-    acc = dict(ms_int=sum(st.ms_intersect for st in stats), ms_mesh=sum(st.ms_mesh for st in stats),
-               ms_shade=sum(st.ms_shade for st in stats), ms_tail=sum(st.ms_tail for st in stats),
-               ms_raygen=sum(st.ms_raygen for st in stats), n_int=sum(st.n_intersect_launches for st in stats),
-               n_mesh=sum(st.n_mesh_launches for st in stats), int_rays=sum(st.intersect_rays for st in stats),
-               mesh_rays=sum(st.mesh_rays for st in stats), mesh_records=sum(st.mesh_records for st in stats),
-               mesh_one_rays=sum(st.mesh_one_rays for st in stats))
     if args.timed_only:
         dt_plain = dt
     else:
@@ -291,30 +286,51 @@ def main():
     if rank == 0:
         value = rays_total / dt / 1e6
         ms_step = dt / args.steps * 1e3
+
         def line(kernel, rays_k, bytes_per_ray, ms, launches):
             ach = rays_k * bytes_per_ray / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch":
                     rays_k / launches if launches else None, "avg_launch_ms": ms / launches if launches else None,
                     "launches": launches, "ms_per_step": ms / args.steps}
-        # which mesh kernel walked the grids (rt_stats.mesh_one_rays): k_mesh_one writes 12 bytes per ray, k_mesh 52
-        one = acc["mesh_rays"] > 0 and acc["mesh_one_rays"] == acc["mesh_rays"]
-        mesh_kernel, mesh_bytes = ("k_mesh_one", BYTES_PER_RAY_MESH_ONE) if one else ("k_mesh", BYTES_PER_RAY_MESH)
-        kernels = [line(mesh_kernel, acc["mesh_rays"], mesh_bytes, acc["ms_mesh"], acc["n_mesh"]),
-                   line("k_intersect", acc["int_rays"], BYTES_PER_RAY_INTERSECT, acc["ms_int"], acc["n_int"]),
-                   line("k_shade", acc["mesh_records"], BYTES_PER_RAY_SHADE_ONE if one else BYTES_PER_RAY_SHADE, acc["ms_shade"], acc["n_int"])]
-        # HBM bytes per k_mesh launch from the PMC passes over this same command (tools/pmc.sh, tools/traffic.py).
-        # The file records the kernel sources it was measured on; after any change to them the figure is
-        # withheld (null) rather than quoted stale.
+
+        def kernel_lines(sts):
+            """the frame's kernels from a leg's rt_stats (HIP events on the launch stream, summed per stage)"""
+            a = dict(ms_int=sum(st.ms_intersect for st in sts), ms_mesh=sum(st.ms_mesh for st in sts),
+                     ms_shade=sum(st.ms_shade for st in sts), ms_tail=sum(st.ms_tail for st in sts),
+                     n_int=sum(st.n_intersect_launches for st in sts), n_mesh=sum(st.n_mesh_launches for st in sts),
+                     int_rays=sum(st.intersect_rays for st in sts), mesh_rays=sum(st.mesh_rays for st in sts),
+                     mesh_records=sum(st.mesh_records for st in sts), mesh_one_rays=sum(st.mesh_one_rays for st in sts),
+                     rays=sum(st.rays for st in sts))
+            # which mesh kernel walked the grids (rt_stats.mesh_one_rays): k_mesh_one writes 12 bytes per ray, k_mesh 52
+            one = a["mesh_rays"] > 0 and a["mesh_one_rays"] == a["mesh_rays"]
+            mesh_kernel, mesh_bytes = ("k_mesh_one", BYTES_PER_RAY_MESH_ONE) if one else ("k_mesh", BYTES_PER_RAY_MESH)
+            tail_rays = a["rays"] - a["int_rays"]  # segments the one-launch tail traced (the passes counted the others)
+            ks = [line("k_intersect", a["int_rays"], BYTES_PER_RAY_INTERSECT, a["ms_int"], a["n_int"]),
+                  line(mesh_kernel, a["mesh_rays"], mesh_bytes, a["ms_mesh"], a["n_mesh"]),
+                  line("k_shade", a["mesh_records"], BYTES_PER_RAY_SHADE_ONE if one else BYTES_PER_RAY_SHADE, a["ms_shade"], a["n_int"]),
+                  line("k_tail", tail_rays, BYTES_PER_RAY_TAIL, a["ms_tail"], len(sts))]
+            return ks
+
+        # The roofline object: the frame's dominant kernel by GPU time, from the leg that renders ONE FRAME AT A TIME,
+        # where a launch has the GPU to itself and its HIP-event duration is its own (with frames in flight a launch
+        # shares the GPU with the other frames' kernels and its event time is not evidence of anything).
+        ks_alone = kernel_lines(alone)
+        roof = dict(max(ks_alone, key=lambda k: k["ms_per_step"]))
+        # HBM bytes per launch from the PMC passes over the same command one frame at a time (tools/pmc.sh,
+        # tools/traffic.py).  The file records the kernel sources it was measured on; after any change to them the
+        # figure is withheld (null) rather than quoted stale.
         traffic, traffic_note = None, "no PMC measurement committed"
         tj = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        fresh = False
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("sources_sha256") == kernel_sources_sha():
-                    traffic = tj.get(mesh_kernel + "_hbm_bytes_per_launch")
+                fresh = tj.get("sources_sha256") == kernel_sources_sha()
+                if fresh:
+                    traffic = tj.get(roof["kernel"] + "_hbm_bytes_per_launch") or tj.get(roof["kernel"] + "_grid_hbm_bytes_per_launch")
                     traffic_note = "profiles/traffic.json, measured on these kernel sources"
                 else:
                     traffic_note = "profiles/traffic.json was measured on other kernel sources: withheld"
@@ -322,60 +338,70 @@ def main():
                 traffic = None
         # The other side of the roofline (FP64 VALU, 78.6 TFLOP/s vector peak = 1024 SIMDs x one 64-lane
         # instruction per 4 cycles): wave-level VALU instructions per frame from the SQ pass of the same profile, over
-        # this run's frame time.  Instructions, not flops: a bound from above on both counts.
+        # the time of a frame alone.  Instructions, not flops: a bound from above on both counts.
         valu = None
+        frame_alone_s = dt_alone / args.steps
         try:
-            if tj.get("sources_sha256") == kernel_sources_sha():
+            if fresh:
                 per = {k[:-len("_valu_wave_instructions_per_frame")]: v for k, v in tj.items() if k.endswith("_valu_wave_instructions_per_frame")}
                 if per and args.scene == SCENE and args.width == WIDTH and args.height == HEIGHT and args.samples == SAMPLES:
                     insts = sum(per.values()) / max(1, world)   # per GPU: the frame's rays are split over the ranks
                     lanes = sum(v * tj.get(k + "_valu_lanes_per_instruction", 0.0) for k, v in per.items()) / max(1, world)
                     peak_issue = VALU_PEAK_TFLOPS * 1e12 / 128.0  # wave instructions per second (an FMA on 64 lanes = 128 flop)
                     valu = {"bound": "fp64 valu issue", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "wave_instructions_per_frame": per, "issue_slots_used": insts / (dt / args.steps) / peak_issue,
+                            "wave_instructions_per_frame": per,
+                            "issue_slots_used_frames_in_flight": insts / (dt / args.steps) / peak_issue,
+                            "issue_slots_used_one_frame_at_a_time": insts / frame_alone_s / peak_issue,
                             "tflops_if_every_lane_instruction_were_an_fma": lanes * 2.0 / (dt / args.steps) / 1e12,
                             "frac": lanes * 2.0 / (dt / args.steps) / 1e12 / VALU_PEAK_TFLOPS,
                             "lanes_per_instruction": {k: tj.get(k + "_valu_lanes_per_instruction") for k in per},
                             "source": "profiles/traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the same command, one frame at a time)"}
+                    dom = roof["kernel"]
+                    if dom in per and roof["ms_per_step"] > 0:
+                        roof["limited_by"] = ("fp64 valu issue: %.0f M wave instructions per frame in %.3f ms = %.0f %% of the chip's 614 G/s issue "
+                                              "peak at %.1f of 64 lanes per instruction" % (
+                                                  per[dom] / 1e6, roof["ms_per_step"], 100.0 * per[dom] / (roof["ms_per_step"] * 1e-3) / peak_issue,
+                                                  tj.get(dom + "_valu_lanes_per_instruction", 0.0)))
         except Exception:
             valu = None
-        roof = dict(kernels[0])
         roof["traffic"] = traffic
         roof["traffic_source"] = traffic_note
-        roof["note"] = ("ms_mesh is the k_mesh + k_mesh_brute stage, HIP events of the timed region: with %d frames in flight a "
-                        "launch shares the GPU with the other frames' kernels while it runs; `one_frame_at_a_time` holds the "
-                        "same figure with the GPU to itself.  k_mesh is bound by VALU issue at low lane occupancy, not by HBM "
-                        "(DESIGN.md): its HBM fraction is low by construction" % F)
-        roof["kernel_note"] = "the mesh stage: k_mesh_one in a scene with one mesh job (rt_k_mesh_pool.h), k_mesh otherwise; rt_stats.mesh_one_rays says which"
-        ms_mesh_alone = sum(st.ms_mesh for st in alone)
-        mesh_rays_alone = sum(st.mesh_rays for st in alone)
-        n_mesh_alone = sum(st.n_mesh_launches for st in alone)
+        roof["measured"] = ("HIP events on the launch stream inside the one-frame-at-a-time leg of this run (%d steps): a launch has the GPU to "
+                            "itself there.  achieved = algorithmic_bytes_per_ray x rays_per_launch / avg_launch_ms; the same kernel's average in "
+                            "profiles/r03_*_alone_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --in-flight 1) must agree" % args.steps)
+        roof["kernel_note"] = ("the frame's dominant kernel by GPU time; k_intersect: nearest analytic hit and the shading of every ray with no "
+                               "mesh to visit; the mesh stage is k_mesh_one in a scene with one mesh job (rt_k_mesh_pool.h), k_mesh otherwise")
         rays_alone = sum(st.rays for st in alone) * (world if world > 1 else 1)  # (rank 0's share times ranks: an estimate for N > 1)
         frame_bytes = rays_total * BYTES_PER_RAY_FRAME + args.width * args.height * args.samples * BYTES_PER_PIXEL_SAMPLE * args.steps
+        frame_bytes_alone = rays_alone * BYTES_PER_RAY_FRAME + args.width * args.height * args.samples * BYTES_PER_PIXEL_SAMPLE * args.steps
+        ks_flight = kernel_lines(stats)
         out = {
             "metric": "Mrays/sec (primary+secondary) at 4K, mesh.scene",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            # BASELINE's metric also asks for the frame time: one frame at a time, first launch to finished frame
+            "frame_time_ms": dt_alone / args.steps * 1e3,
             "config": {"workload": "%s.scene %dx%d samples=%d max_depth=50, seed=1+step" %
                                    (args.scene, args.width, args.height, args.samples),
                        "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps,
                        "frames_in_flight": F, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)},
             "roofline": roof,
             "roofline_valu": valu,
-            "kernels": kernels[1:],
+            "kernels": [k for k in ks_alone if k["kernel"] != roof["kernel"]],
             # the same K steps again without the per-kernel events of the timed region (what rt_render costs a caller
             # that does not ask for stage times)
             "uninstrumented": {"value": rays_total / dt_plain / 1e6, "unit": "Mrays/s", "ms_per_step": dt_plain / args.steps * 1e3},
-            # the same K steps one frame after the other: the latency of a frame, and k_mesh with the GPU to itself
+            # the same K steps one frame after the other: the latency of a frame; the roofline figures above come from this leg
             "one_frame_at_a_time": {"ms_per_step": dt_alone / args.steps * 1e3, "value": rays_alone / dt_alone / 1e6, "unit": "Mrays/s",
-                                    "k_mesh": line(mesh_kernel, mesh_rays_alone, mesh_bytes, ms_mesh_alone, n_mesh_alone)},
-            "stage_ms_per_step": {"raygen": acc["ms_raygen"] / args.steps, "intersect": acc["ms_int"] / args.steps,
-                                  "mesh": acc["ms_mesh"] / args.steps, "shade": acc["ms_shade"] / args.steps,
-                                  "tail": acc["ms_tail"] / args.steps},
+                                    "kernel_ms_per_step": {k["kernel"]: k["ms_per_step"] for k in ks_alone}},
+            # HIP-event stage times of the timed region.  With frames in flight they overlap other frames' kernels and
+            # sum to more than ms_per_step: kept for comparison between runs, not as durations
+            "overlapped_stage_ms_per_step": {k["kernel"]: k["ms_per_step"] for k in ks_flight} if F > 1 else None,
             "frame_hbm": {"bytes_per_ray": BYTES_PER_RAY_FRAME, "bytes_per_pixel_sample": BYTES_PER_PIXEL_SAMPLE,
                           "achieved": frame_bytes / dt / 1e9 / world, "unit": "GB/s per GPU",
-                          "frac": frame_bytes / dt / 1e9 / world / HBM_PEAK_GBS},
+                          "frac": frame_bytes / dt / 1e9 / world / HBM_PEAK_GBS,
+                          "one_frame_at_a_time_frac": frame_bytes_alone / dt_alone / 1e9 / world / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             allc, one = cpu_baseline(args.scene)

@@ -10,5 +10,6 @@ python - <<'PY'
 import json
 for l in open("gpurun_out/configs_csg.jsonl"):
     j = json.loads(l)
-    print("%-70s %8.0f Mrays/s %9.2f ms/frame  stages %s" % (j["config"]["workload"], j["value"], j["ms_per_step"], {k: round(v, 2) for k, v in j["stage_ms_per_step"].items()}))
+    a = j["one_frame_at_a_time"]
+    print("%-70s %8.0f Mrays/s %9.2f ms/frame | one frame at a time %8.0f Mrays/s %9.2f ms  kernels %s" % (j["config"]["workload"], j["value"], j["ms_per_step"], a["value"], a["ms_per_step"], {k: round(v, 2) for k, v in a["kernel_ms_per_step"].items()}))
 PY

@@ -10,10 +10,9 @@ for s in "" "${set_list[@]}"; do
   python - "${s:-default}" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2])
-s = d["stage_ms_per_step"]
-a = d.get("one_frame_at_a_time") or {}
-print("%-36s %7.1f Mrays/s  %.3f ms (plain %.3f)  alone %.3f ms, k_mesh alone %.3f" % (
-    sys.argv[1], d["value"], d["ms_per_step"], d["uninstrumented"]["ms_per_step"], a.get("ms_per_step", 0.0),
-    (a.get("k_mesh") or {}).get("ms_per_step", 0.0)))
+a = d["one_frame_at_a_time"]
+print("%-36s %7.1f Mrays/s  %.3f ms (plain %.3f)  alone %.3f ms: %s" % (
+    sys.argv[1], d["value"], d["ms_per_step"], d["uninstrumented"]["ms_per_step"], a["ms_per_step"],
+    " ".join("%s %.3f" % kv for kv in a["kernel_ms_per_step"].items())))
 PY
 done

@@ -8,6 +8,6 @@ for v in "$@"; do
 import json
 l=[x for x in open("gpurun_out/sweep.log") if x.startswith("{")][-1]
 j=json.loads(l)
-print("$var=$v", "Mrays/s %.0f" % j["value"], "ms/step %.3f" % j["ms_per_step"], " ".join("%s %.3f" % kv for kv in j["stage_ms_per_step"].items()))
+print("$var=$v", "Mrays/s %.0f" % j["value"], "ms/step %.3f" % j["ms_per_step"], " ".join("%s %.3f" % kv for kv in j["one_frame_at_a_time"]["kernel_ms_per_step"].items()))
 PY
 done

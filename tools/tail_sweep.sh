@@ -5,8 +5,8 @@ for setting in "$@"; do
   out=$(env $setting timeout -k 10 150 python bench.py --no-cpu-baseline --steps 12 --warmup 3 $BENCH_ARGS 2>/dev/null) || { echo "$setting failed"; exit 1; }
   python - "$setting" "$out" <<'PY'
 import json, sys
-d = json.loads(sys.argv[2]); s = d["stage_ms_per_step"]; a = d["one_frame_at_a_time"]
-print("%-44s in flight %7.0f Mrays/s %.3f ms | alone %.3f ms %6.0f Mrays/s | stages int %.2f mesh %.2f shade %.2f tail %.2f" % (
-    sys.argv[1], d["value"], d["ms_per_step"], a["ms_per_step"], a["value"], s["intersect"], s["mesh"], s["shade"], s["tail"]), flush=True)
+d = json.loads(sys.argv[2]); a = d["one_frame_at_a_time"]
+print("%-44s in flight %7.0f Mrays/s %.3f ms | alone %.3f ms %6.0f Mrays/s | alone, per kernel: %s" % (
+    sys.argv[1], d["value"], d["ms_per_step"], a["ms_per_step"], a["value"], " ".join("%s %.3f" % kv for kv in a["kernel_ms_per_step"].items())), flush=True)
 PY
 done

@@ -7,8 +7,9 @@ for lib in raytracer_amd/librt_amd.so variants/*.so; do
   python - "$lib" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2])
-s = d["stage_ms_per_step"]
-print("%-28s %7.1f Mrays/s  %.3f ms (plain %.3f)  int %.3f mesh %.3f shade %.3f tail %.3f" % (
-    sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], d["uninstrumented"]["ms_per_step"], s["intersect"], s["mesh"], s["shade"], s["tail"]))
+a = d["one_frame_at_a_time"]
+print("%-28s %7.1f Mrays/s  %.3f ms (plain %.3f) | alone %.3f ms: %s" % (
+    sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], d["uninstrumented"]["ms_per_step"], a["ms_per_step"],
+    " ".join("%s %.3f" % kv for kv in a["kernel_ms_per_step"].items())))
 PY
 done
