@@ -436,16 +436,28 @@ RT_DEV void leaf_surface(const DevLeaf &L, const LeafRay &ry, d3 q, uint32_t tag
 }
 
 // ---------------------------------------------------------------------------
-// Interval lists: end points (t, tag), 2 per interval.
-struct IvList {
-    double t[2 * DEV_MAX_INTERVALS];
-    uint32_t tag[2 * DEV_MAX_INTERVALS];
+// Interval lists: end points (t, tag), 2 per interval.  The lists of a ray live in scratch memory (they are indexed
+// by run-time values), and a launch's waves together hold waves x 64 x (lists x bytes) of it: with 12 intervals per
+// list and 10 lists that is 2.9 KB per lane and 600 MB over the chip - far beyond the caches, so every list access
+// went to HBM (room.scene 4K: 6.0 GB of HBM traffic per k_intersect launch against 1.1 GB algorithmic).  The capacity
+// is a template parameter: scenes whose CSG trees provably never hold more than DEV_SMALL_INTERVALS intervals in a
+// list nor more than DEV_SMALL_STACK lists at once (every scene the reference ships; the flattener bounds both from
+// the tree, rt_flatten.cpp interval_need / stack_need) can run kernels instantiated with those, 864 bytes per lane
+// (-DRT_CSG_SMALL_KERNELS=1).  Measured, the capacity is not what costs: only the entries a ray stores travel, and
+// those are the same - see csg_eval, which stores each list once, and rt_kernels.hip for the numbers.
+template <int MAXI>
+struct IvListT {
+    static constexpr int CAP = MAXI;
+    double t[2 * MAXI];
+    uint32_t tag[2 * MAXI];
     int n; // intervals
 };
+typedef IvListT<DEV_MAX_INTERVALS> IvList;
 
-RT_DEV void iv_push(IvList &l, double t0, uint32_t g0, double t1, uint32_t g1, Guards &gd)
+template <class LST>
+RT_DEV void iv_push(LST &l, double t0, uint32_t g0, double t1, uint32_t g1, Guards &gd)
 {
-    if (l.n >= DEV_MAX_INTERVALS) {
+    if (l.n >= LST::CAP) {
         gd.overflow++;
         return;
     }
@@ -456,10 +468,11 @@ RT_DEV void iv_push(IvList &l, double t0, uint32_t g0, double t1, uint32_t g1, G
     l.n++;
 }
 
-RT_DEV void iv_copy(IvList &dst, const IvList &src)
+template <class LST>
+RT_DEV void iv_copy(LST &dst, const LST &src)
 {
     dst.n = src.n;
-    for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
+    for (int i = 0; i < 2 * LST::CAP; ++i) {
         if (i >= 2 * src.n) break;
         dst.t[i] = src.t[i];
         dst.tag[i] = src.tag[i];
@@ -468,7 +481,8 @@ RT_DEV void iv_copy(IvList &dst, const IvList &src)
 
 // `intervals.sort_by(partial_cmp)`: stable, lexicographic on (entry.t, exit.t).
 // Returns false where the reference would panic on a NaN.
-RT_DEV bool iv_sort(IvList &l)
+template <class LST>
+RT_DEV bool iv_sort(LST &l)
 {
     if (l.n > 1) {
         for (int i = 0; i < 2 * l.n; ++i)
@@ -495,14 +509,15 @@ RT_DEV bool iv_sort(IvList &l)
 
 // csg.rs:28-98 / 133-176 / 211-280 on (t, tag) end points.  Returns false on a
 // reference panic.
-RT_CSG_FN bool csg_apply(int op, const IvList &A, const IvList &B, IvList &out, Guards &gd)
+template <class LST>
+RT_CSG_FN bool csg_apply(int op, const LST &A, const LST &B, LST &out, Guards &gd)
 {
     out.n = 0;
     // The number of intervals written lives in a register (`n_out`) and reaches out.n once, at the end.
     int n_out = 0;
 #define PUSH(T0, G0, T1, G1)                                                                                           \
     do {                                                                                                               \
-        if (n_out >= DEV_MAX_INTERVALS) {                                                                              \
+        if (n_out >= LST::CAP) {                                                                                       \
             gd.overflow++;                                                                                             \
         } else {                                                                                                       \
             out.t[2 * n_out] = (T0);                                                                                   \
@@ -557,7 +572,7 @@ RT_CSG_FN bool csg_apply(int op, const IvList &A, const IvList &B, IvList &out, 
     } while (0)
     int guard_iter = 0;
     while (ia < A.n && ib < B.n) {
-        if (++guard_iter > 8 * DEV_MAX_INTERVALS) break; // cannot happen; keeps the loop provably finite
+        if (++guard_iter > 8 * LST::CAP) break; // cannot happen; keeps the loop provably finite
         if (op == DEV_OP_UNION) {
             if (ae < bs) {
                 PUSH(as, asg, ae, aeg);
@@ -649,8 +664,8 @@ RT_CSG_FN bool csg_apply(int op, const IvList &A, const IvList &B, IvList &out, 
 }
 
 // Intervals of one leaf as world-space end points
-template <bool TORUS>
-RT_DEV void leaf_world_intervals(const DevLeaf &L, uint32_t rel, d3 ow, d3 dw, IvList &out, Guards &gd)
+template <bool TORUS, class LST>
+RT_DEV void leaf_world_intervals(const DevLeaf &L, uint32_t rel, d3 ow, d3 dw, LST &out, Guards &gd)
 {
     LeafRay ry = to_leaf(L, ow, dw);
     double t[4];
@@ -673,46 +688,73 @@ RT_DEV double skip_scale(const DevLeaf &Q, d3 dw)
     return len3(xf_dir(Q.W, dw)) / len3(dp);
 }
 
-// Evaluate an object's postfix program; the result is left in `res`.
-template <bool TORUS>
-RT_CSG_FN bool csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, IvList &res, Guards &gd)
+// Evaluate an object's postfix program on the caller's lists `stack` (STK + 1 of them); returns the index of the
+// list that holds the result, or -1 (the reference would have panicked, or the program is malformed).
+// The lists live in scratch memory, and with thousands of waves in flight that memory is far larger than the caches:
+// every list entry stored goes to HBM (room.scene 4K: 4.0 GB written per k_intersect launch, 570 bytes per ray, all
+// of it list stores).  So nothing is stored twice: an operation writes its result into the one list that is free
+// (never an operand) and the stack entries are renamed - `perm` holds, four bits per stack position, which list a
+// position uses - instead of copied; the result is read where it lies.
+template <bool TORUS, int STK, class LST>
+RT_CSG_FN int csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, LST *stack, Guards &gd)
 {
-    IvList stack[DEV_CSG_STACK];
-    IvList tmp;
+    static_assert(STK + 1 <= 16, "four bits per stack position");
+    uint64_t perm = 0xFEDCBA9876543210ull; // position k uses list (perm >> 4k) & 15
+    int free_list = STK;
     int sp = 0;
+#define CSG_LIST(POS) ((int)((perm >> (4 * (POS))) & 15ull))
     for (int pc = 0; pc < ob.prog_len; ++pc) {
         int word = sc.prog[ob.prog0 + pc];
         int op = (word >> 24) & 0x7F;
         if (op == DEV_OP_LEAF) {
-            if (sp >= DEV_CSG_STACK) {
+            if (sp >= STK) {
                 gd.overflow++;
-                return false;
+                return -1;
             }
             uint32_t rel = (uint32_t)(word & 0xFFFFFF);
-            leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0 + rel], rel, ow, dw, stack[sp], gd);
+            leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0 + rel], rel, ow, dw, stack[CSG_LIST(sp)], gd);
             ++sp;
         } else {
-            if (sp < 2) return false;
-            const bool one_missed = stack[sp - 2].n == 0 || stack[sp - 1].n == 0;
-            if (!csg_apply(op, stack[sp - 2], stack[sp - 1], tmp, gd)) return false;
-            if ((word & DEV_PROG_SKIP) && one_missed && tmp.n > 0) {
+            if (sp < 2) return -1;
+            const int la = CSG_LIST(sp - 2), lb = CSG_LIST(sp - 1);
+            const int na = stack[la].n, nb = stack[lb].n;
+            const bool one_missed = na == 0 || nb == 0;
+            // an operand missed: the result is one of the operands as it stands (csg_apply's own first lines, csg.rs:
+            // 33-38,137-139,216-221) - taken by renaming, not by copying
+            int lr = free_list;
+            if (op == DEV_OP_UNION)
+                lr = na == 0 ? lb : (nb == 0 ? la : free_list);
+            else if (op == DEV_OP_INTERSECTION)
+                lr = na == 0 ? la : (nb == 0 ? lb : free_list);
+            else
+                lr = one_missed ? la : free_list;
+            if (lr == free_list && !csg_apply(op, stack[la], stack[lb], stack[free_list], gd)) return -1;
+            LST &out = stack[lr];
+            if ((word & DEV_PROG_SKIP) && one_missed && out.n > 0) {
                 // csg.rs:33-38,216-221: the surviving operand's end points keep this node's space
                 const DevLeaf &Q = sc.leaves[ob.leaf0 + (word & 0xFFFF)];
                 const double f = skip_scale(Q, dw);
                 const uint32_t bit = 1u << (TAG_SKIP_SHIFT + Q.skip_ord - 1);
-                for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
-                    if (i >= 2 * tmp.n) break;
-                    tmp.t[i] *= f;
-                    tmp.tag[i] |= bit;
+                for (int i = 0; i < 2 * LST::CAP; ++i) {
+                    if (i >= 2 * out.n) break;
+                    out.t[i] *= f;
+                    out.tag[i] |= bit;
                 }
             }
-            iv_copy(stack[sp - 2], tmp);
+            // position sp - 2 now uses the list that holds the result; the positions stay a permutation of the lists
+            const int sh = 4 * (sp - 2);
+            if (lr == free_list) {
+                perm = (perm & ~(15ull << sh)) | ((uint64_t)free_list << sh);
+                free_list = la;
+            } else if (lr == lb) {
+                perm = (perm & ~(255ull << sh)) | ((uint64_t)lb << sh) | ((uint64_t)la << (sh + 4));
+            }
             --sp;
         }
     }
-    if (sp != 1) return false;
-    iv_copy(res, stack[0]);
-    return true;
+#undef CSG_LIST
+    if (sp != 1) return -1;
+    return (int)(perm & 15ull);
 }
 
 // ---------------------------------------------------------------------------

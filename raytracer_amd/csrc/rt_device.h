@@ -200,6 +200,8 @@ struct DevScene {
 #define DEV_MAX_LEAVES_PER_OBJECT 256
 #define DEV_MAX_INTERVALS 12  // per list (beyond: counted in rt_stats.interval_overflow, the object is a miss for that ray)
 #define DEV_CSG_STACK 8       // lists alive at once: right-nested operations need one each, checked at rt_scene_create
+#define DEV_SMALL_INTERVALS 4 // the same two limits of the kernels instantiated for scenes that provably stay within them
+#define DEV_SMALL_STACK 4     // (rt_dev_shapes.h, IvListT): a fifth of the scratch memory per ray
 #define DEV_GRID_MAX_WORDS 2048 // occupancy words of all meshes together: 16 KB of LDS with their ranks, 32 KB of distances
 #define DEV_GRID_MAX_STARTS 6144 // cell_start entries kept in LDS (24 KB); beyond that they are read from memory
 #define DEV_GRID_MAX_AXIS 255

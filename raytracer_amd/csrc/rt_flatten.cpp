@@ -468,12 +468,37 @@ struct Flattener {
         return li;
     }
 
-    void check_stack(int idx) const
+    void check_stack(int idx)
     {
         const int need = stack_need(idx);
         if (need > DEV_CSG_STACK)
             throw Err{RT_ERR_UNSUPPORTED, "CSG tree needs " + std::to_string(need) + " interval lists at once (the device keeps " +
                                               std::to_string(DEV_CSG_STACK) + "): nest the operations on the first operand instead"};
+        out.max_stack = std::max(out.max_stack, need);
+        out.max_intervals = std::max(out.max_intervals, interval_need(idx));
+    }
+
+    // most intervals any list can hold while the subtree is evaluated (its own result and its operands'):
+    // a primitive is one interval, a torus up to two (torus.rs:88-125); a union or a difference of lists of a and b
+    // intervals has at most a + b (each interval of b can split one of a), an intersection a + b - 1 (csg.rs)
+    int interval_need(int idx, int depth = 0, int *result = nullptr) const
+    {
+        if (depth > 4096) throw Err{RT_ERR_INVALID, "shape tree too deep (or cyclic)"};
+        const rt_shape_node &nd = node(idx);
+        int mine = 1, most = 1;
+        if (nd.kind == RT_SHAPE_MEDIUM) {
+            most = interval_need(nd.child_a, depth + 1, &mine);
+        } else if (nd.kind == RT_SHAPE_UNION || nd.kind == RT_SHAPE_INTERSECTION || nd.kind == RT_SHAPE_DIFFERENCE) {
+            int a = 1, b = 1;
+            const int ma = interval_need(nd.child_a, depth + 1, &a), mb = interval_need(nd.child_b, depth + 1, &b);
+            mine = nd.kind == RT_SHAPE_INTERSECTION ? a + b - 1 : a + b;
+            if (mine > 1 << 20) mine = 1 << 20;
+            most = std::max(std::max(ma, mb), mine);
+        } else {
+            mine = most = nd.kind == RT_SHAPE_TORUS ? 2 : 1;
+        }
+        if (result) *result = mine;
+        return most;
     }
 
     // interval lists alive at once while the subtree is evaluated (a, then b, then the operation)

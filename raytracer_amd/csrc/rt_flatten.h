@@ -35,6 +35,7 @@ struct FlatScene {
     double cam_fov_factor;
     double cam_c2w[16];
     bool uses_csg = false;
+    int max_stack = 0, max_intervals = 0; // over all CSG programs / fog boundaries: lists alive at once, intervals in a list (bounds)
     double grid_crowd = 0.0; // worst mesh: triangles in the cell of an average (cell, triangle) reference
 };
 

@@ -13,7 +13,8 @@ struct Candidate {
 };
 
 // first_positive_intersection / first_intersection (shapes/mod.rs:45-55) over a list
-RT_DEV Candidate pick_from_list(const IvList &l, int mode)
+template <class LST>
+RT_DEV Candidate pick_from_list(const LST &l, int mode)
 {
     Candidate c;
     c.ok = false;
@@ -26,7 +27,7 @@ RT_DEV Candidate pick_from_list(const IvList &l, int mode)
         c.ok = true;
         return c;
     }
-    for (int i = 0; i < 2 * DEV_MAX_INTERVALS; ++i) {
+    for (int i = 0; i < 2 * LST::CAP; ++i) {
         if (i >= 2 * l.n) break;
         if (!(l.t[i] < 0.0)) {
             c.t = l.t[i];
@@ -74,17 +75,19 @@ RT_DEV Candidate eval_leaf_object(const DevScene &sc, const DevObject &ob, d3 o,
     return c;
 }
 
-template <bool TORUS>
+// SMALL: the scene's lists fit DEV_SMALL_INTERVALS / DEV_SMALL_STACK (IvListT, rt_dev_shapes.h)
+template <bool TORUS, bool SMALL>
 RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
 {
     Candidate c;
     c.ok = false;
     c.t = 0.0;
     c.aux = 0u;
-    IvList res;
-    res.n = 0;
-    if (!csg_eval<TORUS>(sc, ob, o, d, res, gd)) return c;
-    return pick_from_list(res, ob.mode);
+    constexpr int STK = SMALL ? DEV_SMALL_STACK : DEV_CSG_STACK;
+    IvListT<SMALL ? DEV_SMALL_INTERVALS : DEV_MAX_INTERVALS> lists[STK + 1];
+    const int r = csg_eval<TORUS, STK>(sc, ob, o, d, lists, gd);
+    if (r < 0) return c;
+    return pick_from_list(lists[r], ob.mode);
 }
 
 // Does the ray need the walk through a mesh of this object?  Only a conservative answer is wanted here (k_mesh
@@ -110,7 +113,7 @@ RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3
 }
 
 // HomogenousMedium::intersect (homogenous_medium.rs:29-57)
-template <bool CSG, bool TORUS>
+template <bool CSG, bool TORUS, bool SMALL>
 RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
                                                      d3 d, const PassParams &pp, uint32_t pixel, Guards &gd)
 {
@@ -122,13 +125,18 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
     LeafRay ry = to_leaf(F, o, d);
     // a world-space distance along the ray is `scale` times longer in the medium's space
     double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d));
-    IvList res;
-    res.n = 0;
+    constexpr int STK = SMALL ? DEV_SMALL_STACK : DEV_CSG_STACK;
+    typedef IvListT<SMALL ? DEV_SMALL_INTERVALS : DEV_MAX_INTERVALS> LST;
+    LST lists[CSG ? STK + 1 : 1];
+    int r = 0;
     if (ob.prog_len == 0) {
-        leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, res, gd);
-    } else if (!CSG || !csg_eval<TORUS>(sc, ob, o, d, res, gd)) {
-        return c;
+        lists[0].n = 0;
+        leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, lists[0], gd);
+    } else {
+        r = CSG ? csg_eval<TORUS, STK>(sc, ob, o, d, lists, gd) : -1;
+        if (r < 0) return c;
     }
+    const LST &res = lists[r];
     if (res.n == 0) return c;
     int first = 0;
     while (first < res.n && res.t[2 * first] < 0.0 && res.t[2 * first + 1] < 0.0) ++first; // skip_negative_intervals
@@ -157,7 +165,7 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
 // scene does not need.
 // Ray::trace (system.rs:122-133) over every object except the triangle work; returns whether
 // the ray still has to visit a mesh.
-template <bool CSG, bool MEDIUM, bool TORUS>
+template <bool CSG, bool MEDIUM, bool TORUS, bool SMALL = false>
 RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, const PassParams &pp, HitRec &h, Guards &gd)
 {
     bool wants_mesh = false;
@@ -190,11 +198,11 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
         switch (ob.kind) {
         case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
         case DO_CSG:
-            if (CSG) c = eval_csg_object<TORUS>(sc, ob, o, d, gd);
+            if (CSG) c = eval_csg_object<TORUS, SMALL>(sc, ob, o, d, gd);
             break;
         case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
         default:
-            if (MEDIUM) c = eval_medium_object<CSG, TORUS>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
+            if (MEDIUM) c = eval_medium_object<CSG, TORUS, SMALL>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
             break;
         }
         // Object::intersect keeps t >= 0 (object.rs:50-54)
@@ -275,7 +283,7 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 //    path's colour is added to its pixel.
 // !FUSED (rt_trace_rays): no shading; the hit record of every ray i goes to `hit[i]`, and mesh records carry i
 // in their slot field so that k_copy_mesh_hits can put the merged hit back.
-template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED>
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED, bool SMALL>
 __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
                     thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
                 }
             }
-            wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
+            wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS, SMALL>(sc, o, d, pixel, pp, h, gd);
             if (primary_ids) primary_ids[FUSED ? slot : ray_slot(q, i)] = h.obj;
             if (!FUSED) {
                 hit.t[i] = h.t;

@@ -979,3 +979,38 @@ def test_tail_takeover_is_invisible(rt, monkeypatch):
     monkeypatch.setenv("RT_TAIL_MAX", "100000000")
     r5, i5, s5 = rt.DeviceScene(sc4).render(o)
     assert np.array_equal(r4, r5) and np.array_equal(i4, i5) and s4.rays == s5.rays
+
+
+@pytest.mark.parametrize("name", ["csg", "room", "fog_light", "cylinder"])
+def test_short_interval_lists_change_nothing(rt, monkeypatch, name):
+    """Scenes whose CSG trees provably never hold more than DEV_SMALL_INTERVALS intervals in a list (the flattener
+    bounds it from the tree) can run kernels with short lists in scratch memory (a build with -DRT_CSG_SMALL_KERNELS=1;
+    RT_CSG_SMALL=0 keeps the full-size ones; the default build has only those and this test then compares like with
+    like).  Same frame bit for bit, same rays, no list ever full."""
+    o = rt.Options(width=200, height=150, samples=4, seed=6)
+    sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
+    rgb, ids, st = rt.DeviceScene(sc).render(o)
+    monkeypatch.setenv("RT_CSG_SMALL", "0")
+    rgb2, ids2, st2 = rt.DeviceScene(sc).render(o)
+    assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2)
+    assert st.rays == st2.rays and st.interval_overflow == 0 and st2.interval_overflow == 0
+    assert list(st.guards) == list(st2.guards)
+
+
+def test_wide_union_keeps_full_size_lists(rt):
+    """A union of six spheres along the ray holds six intervals: beyond the short lists, so the scene runs the
+    full-size kernels and nothing overflows (the oracle sees every sphere)."""
+    spheres = ["sphere { origin <%g, 1, 0> radius 0.4 }" % (x * 1.0 - 2.5) for x in range(6)]
+    shape = spheres[0]
+    for sph in spheres[1:]:
+        shape = "union { %s %s }" % (shape, sph)
+    text = ("camera { origin <-6, 1, 0> look_at <0, 1, 0> }\n"
+            "object { sphere { origin <0, 9, 0> radius 3 } material { diffuse_light intensity 4 texture { solid color white } } }\n"
+            "object { %s material { dielectric ior 1.5 } }\n" % shape)
+    o = rt.Options(width=160, height=120, samples=1, seed=2)
+    sc = rt.parse(o, text, parity.ASSETS)
+    rgb, ids, st = rt.DeviceScene(sc).render(o)
+    want, wids, wst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+    assert st.interval_overflow == 0
+    _check(parity.compare(rgb, ids, want, wids, st.strata), st, wst)
+    assert (ids == 1).mean() > 0.01  # the row of spheres is in view, one behind the other

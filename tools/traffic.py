@@ -35,7 +35,8 @@ if len(sys.argv) > 4:
     sq = {}
     for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES"):
         sq[c], _ = per_kernel(sys.argv[4], c)
-    frames = max(1, nf.get("k_tail", 1))  # one k_tail launch per frame of the profiled command
+    # tools/pmc.sh profiles `bench.py --timed-only --in-flight 1 --steps 1 --warmup 1`: two frames
+    frames = int(__import__("os").environ.get("PMC_FRAMES", "2"))
     out["valu_frames_profiled"] = frames
     for k in sorted(sq["SQ_INSTS_VALU"]):
         if not k.startswith("k_") or sq["SQ_ACTIVE_INST_VALU"].get(k, 0.0) <= 0.0:
