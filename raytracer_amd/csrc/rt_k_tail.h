@@ -11,7 +11,7 @@
 // microseconds, plus the host's read-back of the queue length - and the last twenty levels of a 4K mesh.scene
 // frame hold 0.3 % of its rays.  k_tail (rt_k_shade.h) takes those levels in one launch with one WAVE per path
 // and the triangles by brute force, which is right for a few thousand paths; this kernel takes over much
-// earlier (a fraction of the shard's slots, RT_TAIL_FRAC: several hundred thousand paths of a 4K frame): a wave
+// earlier (RT_TAIL_PATHS: as many paths as the chip holds at once, 131 k of a 4K frame's 8.3 M): a wave
 // owns 64 paths, one per lane, and loops intersect -> mesh -> shade until they have all ended.  Nothing is
 // exchanged between waves - no queues, no appends, no counters, no barriers after the tables are staged - so a
 // wave's time is its own paths' and the launch lasts as long as the wave with the deepest path.  Per level:
@@ -28,6 +28,15 @@
 #ifndef RT_TAILG_WAVES
 #define RT_TAILG_WAVES 2
 #endif
+#ifndef RT_TAILG_STEPWISE
+#define RT_TAILG_STEPWISE 0 // 1: the walk in steps at each lane's own pace (rt_k_mesh_grid_step.inc) instead of rounds. Measured on the
+                            // 4K bench frame (131 k paths taken over): 0.553-0.560 ms against 0.493-0.501 with rounds - with the chip full
+                            // of these waves a level is bound by instruction issue, and a wave that executes the walk half and the
+                            // test half in every iteration issues more
+#endif
+#ifndef RT_TAILG_MIN_LANES
+#define RT_TAILG_MIN_LANES 8u // fewest paths a wave takes at a time when few are left
+#endif
 #ifndef RT_TAILG_BRUTE_MAX
 #define RT_TAILG_BRUTE_MAX 6u // lanes wanting the mesh up to which the wave takes them one by one
 #endif
@@ -35,7 +44,7 @@
 #ifdef RT_TAILG_PROF
 // per level (relative to the take-over) and phase (intersect, mesh by grid, mesh by the wave, shade): the slowest
 // wave's time and the sum over waves, in ticks of the 100 MHz wall clock; [4] = waves that ran the level, [5] = their live lanes,
-// [6] = lanes wanting the mesh
+// [6] = lanes wanting the mesh, [7] = rounds of the grid walk
 __device__ unsigned long long g_tg_max[64][4];
 __device__ unsigned long long g_tg_sum[64][8];
 #define TG_MARK(PHASE)                                                                                                 \
@@ -109,9 +118,13 @@ k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, Pas
     gd.overflow = 0u;
     uint32_t my_rays = 0u, my_depth = 0u; // segments traced beyond each path's first, deepest level reached
 
-    for (uint64_t base = (uint64_t)wave * 64u; base < count; base += (uint64_t)n_waves * 64u) {
+    // Few paths: fewer of them per wave, over all the waves the launch has (the host sizes it for the chip) - a wave's
+    // level lasts as long as its slowest lane's walk, and its rounds as long as the longest run of records among its lanes
+    uint32_t per_wave = RT_TAILG_MIN_LANES;
+    while (per_wave < 64u && (uint64_t)per_wave * n_waves < count) per_wave <<= 1;
+    for (uint64_t base = (uint64_t)wave * per_wave; base < count; base += (uint64_t)n_waves * per_wave) {
         const uint64_t i = base + lane_id();
-        bool alive = i < count;
+        bool alive = lane_id() < per_wave && i < count;
         d3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), thr = mk3(0, 0, 0);
         uint32_t slot = 0u, pixel = 0u;
         if (alive) {
@@ -153,6 +166,11 @@ k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, Pas
                 int cx = 0, cy = 0, cz = 0;
                 double mt = 1.0e300;
                 uint32_t mtri = 0xFFFFFFFFu;
+#if RT_TAILG_STEPWISE
+                bool in_cell = false; // the lane is inside a cell's run of records (rt_k_mesh_grid_step.inc)
+                uint32_t lpos = 0u, llast = 0u;
+                float fox = 0.f, foy = 0.f, foz = 0.f;
+#endif
                 if (wants) {
                     const DevMeshJob &J = JOB(0);
                     double scale = 1.0;
@@ -179,7 +197,14 @@ k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, Pas
                     }
                 }
                 while (__ballot(active) != 0ull) {
+#ifdef RT_TAILG_PROF
+                    if (lane_id() == 0u && tg_level < 64u) atomicAdd(&g_tg_sum[tg_level][7], 1ull);
+#endif
+#if RT_TAILG_STEPWISE
+#include "rt_k_mesh_grid_step.inc"
+#else
 #include "rt_k_mesh_grid_round.inc"
+#endif
                 }
                 if (wants && mtri != 0xFFFFFFFFu) (void)mesh_one_finish(sc, wo, wd, mt, mtri, h);
                 TG_MARK(1);

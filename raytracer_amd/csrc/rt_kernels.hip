@@ -606,8 +606,8 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     return walked;
 }
 
-#ifndef RT_TAIL_FRAC
-#define RT_TAIL_FRAC 24u // k_tail_grid takes over when at most 1 / RT_TAIL_FRAC of the shard's slots still hold a path
+#ifndef RT_TAIL_PATHS
+#define RT_TAIL_PATHS 140000u // k_tail_grid takes over when at most this many paths are left: 256 CUs x 4 SIMDs x 2 waves x 64 lanes, and a little
 #endif
 #define RT_TAIL_MAX_TESTS 36000000ull // paths x triangles below which k_tail takes the rest of the stratum (measured)
 
@@ -618,7 +618,11 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
     if (s->tail_grid_lds_bytes != 0u && variant != 8) {
         // one lane per path, the scene's one mesh through its grid: a workgroup per 256 paths (they are not all
         // resident at once when many paths are left; the ones that wait start as the short paths' waves finish)
+        // ... but at least the waves the chip holds at once (256 CUs x 4 SIMDs x RT_TAILG_WAVES) when fewer paths are
+        // left than fill them: the kernel then gives each wave 8 to 32 paths instead of 64
+        const uint64_t resident = 256u * RT_TAILG_WAVES; // workgroups of 4 waves
         uint64_t blocks = ((uint64_t)live + RT_TAILG_LANES - 1) / RT_TAILG_LANES;
+        if (blocks < resident) blocks = std::min<uint64_t>(resident, ((uint64_t)live + (RT_TAILG_LANES / 64) * RT_TAILG_MIN_LANES - 1) / ((RT_TAILG_LANES / 64) * RT_TAILG_MIN_LANES));
         if (blocks > 65535u * 16u) blocks = 65535u * 16u;
         if (blocks < 1) blocks = 1;
 #define LAUNCH_TGS(C, M, T, S)                                                                                         \
@@ -768,14 +772,17 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 // only sizes grids and picks between k_mesh and k_mesh_brute.
                 uint32_t live = n_slots;
                 // Paths left at which one launch takes the rest of the stratum.  k_tail_grid (one lane per path, the
-                // mesh through its grid): a fraction of the shard's slots - the passes below that have a floor of
-                // ~0.1 ms each whatever they hold.  k_tail: one wave per path with the triangles by brute force,
-                // or one lane per path in a scene without meshes.
+                // mesh through its grid): as many as the chip holds at once at two waves per SIMD (RT_TAIL_PATHS;
+                // passes that small have a floor of ~0.1 ms each whatever they hold), but not before the paths have
+                // thinned to a sixth of the shard's slots.  Measured, 4K bench frame / its shard 0 of 8, one frame at
+                // a time: take-over at 600 k paths 3.20 ms, at 131 k 2.67, at 65 k 2.75; shard at 75 k 0.87, at 16 k
+                // 0.92.  k_tail: one wave per path with the triangles by brute force, or one lane per path in a scene
+                // without meshes.
                 const uint32_t tail_env = getenv("RT_TAIL_MAX") ? (uint32_t)atoi(getenv("RT_TAIL_MAX")) : 0xFFFFFFFFu;
-                const uint32_t tail_frac = getenv("RT_TAIL_FRAC") ? (uint32_t)std::max(1, atoi(getenv("RT_TAIL_FRAC"))) : RT_TAIL_FRAC;
+                const uint32_t tail_paths = getenv("RT_TAIL_PATHS") ? (uint32_t)std::max(1, atoi(getenv("RT_TAIL_PATHS"))) : RT_TAIL_PATHS;
                 uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 16384u;
                 if (tail_max > 16384u) tail_max = 16384u;
-                if (s->tail_grid_lds_bytes != 0u && n_slots / tail_frac > tail_max) tail_max = n_slots / tail_frac;
+                if (s->tail_grid_lds_bytes != 0u) tail_max = std::max(tail_max, std::min(n_slots / 6u, tail_paths));
                 if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
                 const uint32_t run_ahead = getenv("RT_RUN_AHEAD") ? (uint32_t)atoi(getenv("RT_RUN_AHEAD")) : 2u;
                 // What the last stratum of this shape did: its passes are queued again without a single wait
@@ -973,9 +980,9 @@ finished:
         double tot = 0.0;
         for (int l = 0; l < 64 && sm[l][4]; ++l) {
             const double w_ = (double)sm[l][4];
-            fprintf(stderr, "[k_tail_grid] level +%2d: waves %6llu lanes/wave %5.1f wanting %5.1f | slowest wave us: isect %6.2f grid %6.2f wave-brute %6.2f shade %6.2f | mean us: %5.2f %5.2f %5.2f %5.2f\n",
+            fprintf(stderr, "[k_tail_grid] level +%2d: waves %6llu lanes/wave %5.1f wanting %5.1f | slowest wave us: isect %6.2f grid %6.2f wave-brute %6.2f shade %6.2f | mean us: %5.2f %5.2f %5.2f %5.2f | grid rounds per wave %5.1f\n",
                     l, sm[l][4], sm[l][5] / w_, sm[l][6] / w_, mx[l][0] / 100.0, mx[l][1] / 100.0, mx[l][2] / 100.0, mx[l][3] / 100.0,
-                    sm[l][0] / w_ / 100.0, sm[l][1] / w_ / 100.0, sm[l][2] / w_ / 100.0, sm[l][3] / w_ / 100.0);
+                    sm[l][0] / w_ / 100.0, sm[l][1] / w_ / 100.0, sm[l][2] / w_ / 100.0, sm[l][3] / w_ / 100.0, sm[l][7] / w_);
             tot += (mx[l][0] + mx[l][1] + mx[l][2] + mx[l][3]) / 100.0;
         }
         fprintf(stderr, "[k_tail_grid] sum of the slowest phases: %.1f us\n", tot);
