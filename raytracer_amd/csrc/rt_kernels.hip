@@ -783,6 +783,13 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 uint32_t tail_max = s->has_mesh ? (uint32_t)(RT_TAIL_MAX_TESTS / (s->n_mesh_tris ? s->n_mesh_tris : 1u)) : 16384u;
                 if (tail_max > 16384u) tail_max = 16384u;
                 if (s->tail_grid_lds_bytes != 0u) tail_max = std::max(tail_max, std::min(n_slots / 6u, tail_paths));
+                if (!s->has_mesh) {
+                    // one lane per path and nothing shared between lanes: the launch lasts as long as its deepest path
+                    // whether it holds 16 k paths or as many as the chip holds at once (the variants with CSG, fog or
+                    // torus code are compiled for one wave per SIMD: 65 k lanes), while every pass it replaces has its floor
+                    const uint32_t resident = (s->has_csg || s->has_medium || s->has_torus) ? 65536u : tail_paths;
+                    tail_max = std::max(tail_max, std::min(n_slots / 6u, std::min(resident, tail_paths)));
+                }
                 if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
                 const uint32_t run_ahead = getenv("RT_RUN_AHEAD") ? (uint32_t)atoi(getenv("RT_RUN_AHEAD")) : 2u;
                 // What the last stratum of this shape did: its passes are queued again without a single wait

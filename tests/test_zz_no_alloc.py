@@ -96,4 +96,7 @@ def test_noalloc_overlapping_calls_are_refused_not_raced(rt):
             done += 1
         else:
             assert rc == _capi.RT_ERR_INVALID and b"another call" in msg, (rc, msg)
-    assert done >= 12  # whoever was not refused rendered correctly; a thread alone on the GPU is never refused
+    assert done >= 1  # a call is only ever refused while another one is running, and that one renders
+    # with the GPU to itself again the entry point is never refused
+    rc, rgb, _, _ = _shard(rt, devs[1], o, True)
+    assert rc == 0 and np.array_equal(rgb, want)
