@@ -28,12 +28,16 @@ import sys
 import time
 
 # One hardware queue per stream that has work at the same time: the frames in flight each own a stream, torch's
-# stream carries the gather, and HIP's default of 4 queues per process would make the fourth frame's stream share
-# one (measured: 4 frames in flight 2.59 ms per frame on 4 queues, 2.31 on 8; 3 frames 2.42 on either).  Read by
-# the HIP runtime when it starts, so it is set before anything touches the GPU; a value from the caller stays (the
-# profiling scripts export the same 8 before rocprofv3, whose preloaded library may start the runtime first).  The
-# value in effect is recorded in the JSON line's config.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# stream carries the gather, and HIP's default of 4 queues per process (which the GPU box also exports) would make the
+# fourth frame's stream share one (measured: 4 frames in flight 2.59 ms per frame on 4 queues, 2.31 on 8; 3 frames 2.42
+# on either).  Read by the HIP runtime when it starts, so it is set before anything touches the GPU.  A larger value
+# from the caller stays; BENCH_HW_QUEUES=<n> asks for exactly n (tools/flight_sweep.sh's 4-queue leg); the profiling
+# scripts export the same 8 before rocprofv3, whose preloaded library may start the runtime before this line runs.
+# The value in effect is recorded in the JSON line's config.
+if os.environ.get("BENCH_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["BENCH_HW_QUEUES"]
+elif int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -145,6 +149,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (with --same-device) rehearses the multi-rank path on a one-GPU box: shards are gathered through host memory")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--gather", default="rgb8", choices=["rgb8", "f64"],
+                    help="what crosses the links in the exchange step of a multi-GPU frame: the shard tone-mapped where it was rendered "
+                         "(main.rs:201-222 is per pixel: 3 bytes per pixel, SURVEY 8e) or its f64 sums (24 bytes per pixel)")
     args = ap.parse_args()
 
     import torch
@@ -183,13 +190,18 @@ def main():
     F = max(1, args.in_flight)
     n_slots = [system.shard_pixels(opts, r, world) for r in range(world)]
     max_slots = max(n_slots)
-    full = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
-    gathered = [torch.zeros(max_slots * 3, dtype=torch.float64, device=dev) for _ in range(world)] \
+    # the exchange step's buffers: f64 sums or tone-mapped bytes (--gather)
+    gdtype = torch.uint8 if args.gather == "rgb8" else torch.float64
+    full = torch.zeros(args.height * args.width * 3, dtype=gdtype, device=dev) if (rank == 0 and world > 1) else None
+    gathered = [torch.zeros(max_slots * 3, dtype=gdtype, device=dev) for _ in range(world)] \
         if (rank == 0 and world > 1) else None
+    sqrt_spp = int(args.samples ** 0.5)
+    divisor = float(sqrt_spp * sqrt_spp + 1)  # the reference's own count: strata + 1 (main.rs:175-222)
     slots = []
     for f in range(F):  # scene upload and buffers: outside the timed region
         out = torch.zeros((max_slots if world > 1 else args.height * args.width) * 3, dtype=torch.float64, device=dev)
-        slots.append({"scene": rt.DeviceScene(scene), "stream": torch.cuda.Stream(device=dev), "out": out})
+        out8 = torch.zeros(max_slots * 3, dtype=torch.uint8, device=dev) if (world > 1 and args.gather == "rgb8") else None
+        slots.append({"scene": rt.DeviceScene(scene), "stream": torch.cuda.Stream(device=dev), "out": out, "out8": out8})
     main_stream = torch.cuda.current_stream().cuda_stream
     pool = ThreadPoolExecutor(F)
 
@@ -198,12 +210,17 @@ def main():
         o = dataclasses.replace(opts, seed=1 + k, stage_times=instrumented)
         torch.cuda.set_device(local_rank)
         # a single GPU writes the row-major image directly (RT_FLAG_ROW_MAJOR): nothing to reassemble
-        return slot["scene"].render_shard(o, rank, world, slot["out"].data_ptr(), None, slot["stream"].cuda_stream,
-                                          row_major=(world == 1))
+        st = slot["scene"].render_shard(o, rank, world, slot["out"].data_ptr(), None, slot["stream"].cuda_stream,
+                                        row_major=(world == 1))
+        if slot["out8"] is not None:
+            # the output stage's pixel math on this rank's tiles, on the frame's own stream: the exchange then moves bytes
+            system.tonemap_device(slot["out"].data_ptr(), n_slots[rank], divisor, slot["out8"].data_ptr(), slot["stream"].cuda_stream)
+            slot["stream"].synchronize()
+        return st
 
     def exchange(k):
         """the one exchange step of frame k: every rank's tiles to rank 0, scattered into the row-major image"""
-        shard = slots[k % F]["out"]
+        shard = slots[k % F]["out8"] if args.gather == "rgb8" else slots[k % F]["out"]
         if args.backend == "nccl":
             dist.gather(shard, gathered, dst=0)
         else:
@@ -215,7 +232,10 @@ def main():
                     gathered[r].copy_(parts[r])
         if rank == 0:
             for r in range(world):
-                system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=main_stream)
+                if args.gather == "rgb8":
+                    system.unshard_rgb8(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=main_stream)
+                else:
+                    system.unshard(opts, r, world, gathered[r].data_ptr(), full.data_ptr(), stream=main_stream)
         torch.cuda.current_stream().synchronize()  # the slot's buffer is free for frame k + F
 
     def run(first, count, instrumented):
@@ -384,7 +404,7 @@ def main():
             "frame_time_ms": dt_alone / args.steps * 1e3,
             "config": {"workload": "%s.scene %dx%d samples=%d max_depth=50, seed=1+step" %
                                    (args.scene, args.width, args.height, args.samples),
-                       "tile": 64, "sharding": "tile%d" % world, "rays_per_frame": rays_total / args.steps,
+                       "tile": 64, "sharding": "tile%d" % world, "gather": (args.gather if world > 1 else None), "rays_per_frame": rays_total / args.steps,
                        "frames_in_flight": F, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)},
             "roofline": roof,
             "roofline_valu": valu,

@@ -264,6 +264,13 @@ extern "C" {
         stats: *mut rt_stats,
         progress: *const rt_progress,
     ) -> c_int;
+    pub fn rt_unshard_rgb8_device(
+        opts: *const rt_options,
+        shard_rank: u32,
+        d_shard_rgb8: *const u8,
+        d_full_rgb8: *mut u8,
+        stream: *mut c_void,
+    ) -> c_int;
     pub fn rt_render_rgb8(
         scene: *mut rt_scene,
         opts: *const rt_options,

@@ -340,6 +340,12 @@ int rt_shard_map(const rt_options *opts, uint32_t *pixel_index);
 int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, const double *d_shard_rgb, double *d_full_rgb,
                       const int32_t *d_shard_ids, int32_t *d_full_ids, void *stream);
 
+/* The same for a shard that was tone-mapped where it was rendered (rt_tonemap_device on the shard's buffer: the pixel
+ * math of main.rs:201-222 is per pixel, so it commutes with the gather): 3 bytes per slot cross the links instead of
+ * 24.  d_shard_rgb8: rt_shard_pixels(opts) x 3 bytes; d_full_rgb8: width x height x 3 bytes, row-major. */
+int rt_unshard_rgb8_device(const rt_options *opts, uint32_t shard_rank, const uint8_t *d_shard_rgb8, uint8_t *d_full_rgb8,
+                           void *stream);
+
 /* Ray::trace (system.rs:122-133) for a batch of world-space rays (host
  * arrays, xyz interleaved).  Directions must have unit length, as every ray of
  * the reference has (camera rays, scattered rays and Ray::transform all

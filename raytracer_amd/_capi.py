@@ -128,6 +128,7 @@ SIGNATURES = {
     "rt_shard_map": (C.c_int, [C.POINTER(rt_options), C.POINTER(C.c_uint32)]),
     "rt_unshard_device": (C.c_int, [C.POINTER(rt_options), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "rt_unshard_rgb8_device": (C.c_int, [C.POINTER(rt_options), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(rt_hit), C.POINTER(rt_stats)]),
     "rt_tonemap": (C.c_int, [C.POINTER(C.c_double), C.c_uint64, C.c_double, C.POINTER(C.c_uint8)]),

@@ -266,6 +266,19 @@ __global__ void k_unshard(rt_shard_geom g, uint32_t rank, uint32_t n_slots, cons
     }
 }
 
+// ... and of a shard that has been tone-mapped where it was rendered (3 bytes per slot instead of 24 across the links)
+__global__ void k_unshard_rgb8(rt_shard_geom g, uint32_t rank, uint32_t n_slots, const uint8_t *__restrict__ shard_rgb8, uint8_t *__restrict__ full_rgb8)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x, y;
+    if (slot < n_slots && rt_shard_decode(&g, rank, slot, &x, &y)) {
+        const size_t p = (size_t)y * g.width + x;
+        full_rgb8[p * 3 + 0] = shard_rgb8[(size_t)slot * 3 + 0];
+        full_rgb8[p * 3 + 1] = shard_rgb8[(size_t)slot * 3 + 1];
+        full_rgb8[p * 3 + 2] = shard_rgb8[(size_t)slot * 3 + 2];
+    }
+}
+
 // The same for all shards of a frame at once (rt_render_multi): their buffers lie one after the other in rank
 // order, `shards_*` is the first.  Tiles are dealt round-robin, so the first n_tiles % N shards own one tile more
 // than the others and a slot's shard follows from its position.

@@ -1069,6 +1069,28 @@ extern "C" int rt_unshard_device(const rt_options *opts, uint32_t shard_rank, co
     return RT_OK;
 }
 
+extern "C" int rt_unshard_rgb8_device(const rt_options *opts, uint32_t shard_rank, const uint8_t *d_shard_rgb8, uint8_t *d_full_rgb8,
+                                      void *stream)
+{
+    int rc = check_options(opts);
+    if (rc) return rc;
+    if (!d_shard_rgb8 || !d_full_rgb8) {
+        rt_host::set_last_error("rt_unshard_rgb8_device: null argument");
+        return RT_ERR_INVALID;
+    }
+    rt_shard_geom g = rt_shard_geom_make(opts->width, opts->height, opts->tile_size, opts->shard_count);
+    if (shard_rank >= g.shard_count) {
+        rt_host::set_last_error("rt_unshard_rgb8_device: shard_rank out of range");
+        return RT_ERR_INVALID;
+    }
+    uint32_t n_slots = rt_shard_tiles(&g, shard_rank) * g.tile_px;
+    if (n_slots == 0) return RT_OK;
+    hipLaunchKernelGGL(k_unshard_rgb8, dim3((n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, shard_rank, n_slots, d_shard_rgb8,
+                       d_full_rgb8);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_tonemap_device(const double *d_rgb_sum, uint64_t n_pixels, double divisor, uint8_t *d_rgb8, void *stream)
 {
     if (!d_rgb_sum || !d_rgb8) {

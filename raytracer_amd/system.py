@@ -309,6 +309,15 @@ def unshard(options, shard_rank, shard_count, d_shard_rgb, d_full_rgb, d_shard_i
     _check(lib, rc, "rt_unshard_device")
 
 
+def unshard_rgb8(options, shard_rank, shard_count, d_shard_rgb8, d_full_rgb8, stream=None):
+    """The same for a shard tone-mapped where it was rendered (rt_unshard_rgb8_device): 3 bytes per slot."""
+    from . import lib
+    o = options.to_c(shard_rank, shard_count)
+    rc = lib.rt_unshard_rgb8_device(C.byref(o), shard_rank, C.c_void_p(d_shard_rgb8), C.c_void_p(d_full_rgb8),
+                                    C.c_void_p(stream) if stream else None)
+    _check(lib, rc, "rt_unshard_rgb8_device")
+
+
 def render(options, scene, progress=None):
     """system::render(options, scene, &mut progress) (system.rs:263-307) on one GPU."""
     dev = DeviceScene(scene)

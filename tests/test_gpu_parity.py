@@ -342,19 +342,25 @@ def test_sharded_render_equals_whole(rt):
     whole, wids, wst = dev.render(o)
     full = torch.zeros(200 * 300 * 3, dtype=torch.float64, device="cuda")
     fids = torch.full((200 * 300,), -5, dtype=torch.int32, device="cuda")
+    full8 = torch.zeros(200 * 300 * 3, dtype=torch.uint8, device="cuda")
     rays = 0
+    cs = torch.cuda.current_stream().cuda_stream
     for r in range(3):
         n = system.shard_pixels(o, r, 3)
         buf = torch.zeros(n * 3, dtype=torch.float64, device="cuda")
         ibuf = torch.zeros(n, dtype=torch.int32, device="cuda")
-        st = dev.render_shard(o, r, 3, buf.data_ptr(), ibuf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        st = dev.render_shard(o, r, 3, buf.data_ptr(), ibuf.data_ptr(), cs)
         rays += st.rays
-        system.unshard(o, r, 3, buf.data_ptr(), full.data_ptr(), ibuf.data_ptr(), fids.data_ptr(),
-                       torch.cuda.current_stream().cuda_stream)
+        system.unshard(o, r, 3, buf.data_ptr(), full.data_ptr(), ibuf.data_ptr(), fids.data_ptr(), cs)
+        # the same shard tone-mapped where it lies (what bench.py sends over the links: 3 bytes per slot), then scattered
+        buf8 = torch.zeros(n * 3, dtype=torch.uint8, device="cuda")
+        system.tonemap_device(buf.data_ptr(), n, st.strata + 1, buf8.data_ptr(), cs)
+        system.unshard_rgb8(o, r, 3, buf8.data_ptr(), full8.data_ptr(), cs)
     torch.cuda.synchronize()
     assert np.array_equal(full.cpu().numpy().reshape(200, 300, 3), whole)
     assert np.array_equal(fids.cpu().numpy().reshape(200, 300), wids)
     assert rays == wst.rays
+    assert np.array_equal(full8.cpu().numpy().reshape(200, 300, 3), rt.tonemap(whole, wst.strata + 1))
     # and the torch-side scatter used after the RCCL gather gives the same image
     buf = torch.zeros(system.shard_pixels(o, 0, 1) * 3, dtype=torch.float64, device="cuda")
     dev.render_shard(o, 0, 1, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)

@@ -49,6 +49,35 @@ def main():
     dt = time.perf_counter() - t0
     print("rt_render to pinned host memory, reused, ids with: %.2f ms per frame, %.0f Mrays/s (%d frames)" % (
         dt / a.steps * 1e3, rays / dt / 1e6, a.steps))
+    # the frame as an image (rt_render_rgb8: tone-mapped on the GPU, 3 bytes per pixel over PCIe), into pinned memory
+    img = torch.zeros((a.height, a.width, 3), dtype=torch.uint8).pin_memory()
+
+    def one8(k):
+        oc = dataclasses.replace(o, seed=1 + k).to_c()
+        rc = ds._lib.rt_render_rgb8(ds._h, C.byref(oc), C.cast(img.data_ptr(), C.POINTER(C.c_uint8)), None, C.byref(stats), None)
+        assert rc == 0, rc
+        return stats.rays
+
+    one8(0)
+    rays = 0
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        rays += one8(k)
+    dt = time.perf_counter() - t0
+    print("rt_render_rgb8 to pinned host memory, reused: %.2f ms per frame, %.0f Mrays/s (%d frames)" % (
+        dt / a.steps * 1e3, rays / dt / 1e6, a.steps))
+    # the Python wrapper with its own page-locked buffers (DeviceScene.render(reuse=True), render_rgb8(reuse=True))
+    for name, call in (("DeviceScene.render(reuse=True), ids with", lambda k: ds.render(dataclasses.replace(o, seed=1 + k), reuse=True)),
+                       ("DeviceScene.render(reuse=True), ids without", lambda k: ds.render(dataclasses.replace(o, seed=1 + k), want_ids=False, reuse=True)),
+                       ("DeviceScene.render_rgb8(reuse=True)", lambda k: ds.render_rgb8(dataclasses.replace(o, seed=1 + k), reuse=True)),
+                       ("DeviceScene.render_rgb8()", lambda k: ds.render_rgb8(dataclasses.replace(o, seed=1 + k)))):
+        call(0)
+        rays = 0
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            rays += call(k)[2].rays
+        dt = time.perf_counter() - t0
+        print("%s: %.2f ms per frame, %.0f Mrays/s (%d frames)" % (name, dt / a.steps * 1e3, rays / dt / 1e6, a.steps))
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@
 # Output: gpurun_out/pmc_<tag>_<n>.csv (per-dispatch counter values).  Run on the GPU box.
 tag=$1; shift
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} # as bench.py sets it: the profiler's preload may start the HIP runtime before bench.py runs
+export GPU_MAX_HW_QUEUES=${BENCH_HW_QUEUES:-8} # as bench.py sets it: the profiler's preload may start the HIP runtime before bench.py runs
 cd $GRAFT_REPO_ROOT
 n=0
 for set in "$@"; do

@@ -5,7 +5,7 @@
 # own run.  Results under gpurun_out/<tag>_*; tools/profile_config_summary.py turns them into profiles/<tag>_summary.txt.
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
+export GPU_MAX_HW_QUEUES=${BENCH_HW_QUEUES:-8}
 timeout -k 10 300 python bench.py --no-cpu-baseline --in-flight 1 "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { echo bench failed; tail -3 gpurun_out/${tag}_bench.err; exit 1; }
 timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_bench_in_flight.json 2>> gpurun_out/${tag}_bench.err || { echo bench in flight failed; exit 1; }
 rm -rf gpurun_out/prof_$tag
