@@ -12,7 +12,7 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-def _shard(rt, dev, o, noalloc, rank=0, count=1):
+def _shard(rt, dev, o, noalloc, rank=0, count=1, check_memory=True):
     import torch
     from raytracer_amd import _capi, system
     n = system.shard_pixels(o, rank, count)
@@ -26,7 +26,7 @@ def _shard(rt, dev, o, noalloc, rank=0, count=1):
     rc = fn(dev._h, C.byref(oc), C.c_void_p(buf.data_ptr()), C.c_void_p(ids.data_ptr()), C.byref(st),
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    if noalloc:
+    if noalloc and check_memory:
         assert torch.cuda.mem_get_info()[0] == free_before, "rt_render_device_noalloc changed the device's free memory"
     return rc, buf.cpu().numpy(), ids.cpu().numpy(), st
 
@@ -41,12 +41,32 @@ def test_noalloc_equals_render_device(rt):
         sc = rt.parse_file(o, parity.scene_path(name), parity.ASSETS)
         dev = rt.DeviceScene(sc)
         scenes[name] = dev
+        # The first launch of a kernel in a process, and of a spilling kernel on a stream, makes the HIP RUNTIME load its
+        # code object and set up scratch memory for the queue: not an allocation of the entry point's, but device memory
+        # all the same, so it happens in a first call that is not measured; from then on the free memory must not move.
+        rc, _, _, _ = _shard(rt, dev, o, True, rank, count, check_memory=False)
+        assert rc == 0, rt.lib.rt_last_error()
         rc, rgb, ids, st = _shard(rt, dev, o, True, rank, count)
         assert rc == 0, rt.lib.rt_last_error()
         rc2, rgb2, ids2, st2 = _shard(rt, dev, o, False, rank, count)
         assert rc2 == 0
         assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2)
         assert st.rays == st2.rays and st.rays > 0 and list(st.guards) == list(st2.guards)
+        if name == "fog_light":
+            # ... and against the oracle itself, not only against the entry point it shares its kernels with
+            import oracle_lib
+            from raytracer_amd import system
+            ref, rids, rst = oracle_lib.render(sc.desc, o.to_c(), threads=16)
+            m = system.shard_map(o, rank, count)
+            got = np.zeros((h * w, 3))
+            got[m[m >= 0]] = rgb.reshape(-1, 3)[m >= 0]
+            gid = np.full(h * w, -1, dtype=np.int32)
+            gid[m[m >= 0]] = ids[m >= 0]
+            res = parity.compare(got.reshape(h, w, 3), gid.reshape(h, w), ref, rids, st.strata)
+            # north_star's bar: ids on >= 99.9 % of the pixels, mean tone-mapped error <= 1/255; the same random numbers on
+            # both sides, so also nearly every pixel to 1e-9 and the ray counts to 0.1 %
+            assert res["id_match"] >= 0.999 and res["mean_err_255"] <= 1.0 and res["px_close"] >= 0.999, res
+            assert abs(st.rays - rst.rays) <= 1e-3 * rst.rays
     # beyond the static array: refused with a clear error, nothing rendered
     o = rt.Options(width=1024, height=768, samples=1, seed=1)
     rc, rgb, ids, st = _shard(rt, scenes["mesh"], o, True)
