@@ -329,7 +329,7 @@ def main():
             ks = [line("k_intersect", a["int_rays"], BYTES_PER_RAY_INTERSECT, a["ms_int"], a["n_int"]),
                   line(mesh_kernel, a["mesh_rays"], mesh_bytes, a["ms_mesh"], a["n_mesh"]),
                   line("k_shade", a["mesh_records"], BYTES_PER_RAY_SHADE_ONE if one else BYTES_PER_RAY_SHADE, a["ms_shade"], a["n_int"]),
-                  line("k_tail", tail_rays, BYTES_PER_RAY_TAIL, a["ms_tail"], len(sts))]
+                  line("k_tail", tail_rays, BYTES_PER_RAY_TAIL, a["ms_tail"], sum(st.strata for st in sts))]  # one tail per stratum
             return ks
 
         # The roofline object: the frame's dominant kernel by GPU time, from the leg that renders ONE FRAME AT A TIME,
