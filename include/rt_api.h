@@ -299,7 +299,8 @@ int rt_render_multi(rt_scene *const *scenes, uint32_t n_devices, const rt_option
  * primary_ids, stats, progress may be NULL; progress snapshots are row-major RGB8 as well. */
 int rt_render_rgb8(rt_scene *scene, const rt_options *opts, uint8_t *rgb8, int32_t *primary_ids, rt_stats *stats,
                    const rt_progress *progress);
-/* The same over n_devices GPUs (rt_render_multi's arguments; the gathered frame is tone-mapped on scenes[0]'s GPU). */
+/* The same over n_devices GPUs (rt_render_multi's arguments): every GPU tone-maps its own tiles before it pushes them,
+ * so 3 bytes per pixel cross the links as well. */
 int rt_render_multi_rgb8(rt_scene *const *scenes, uint32_t n_devices, const rt_options *opts, uint8_t *rgb8,
                          int32_t *primary_ids, rt_stats *stats, const rt_progress *progress);
 

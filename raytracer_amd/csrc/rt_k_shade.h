@@ -310,6 +310,31 @@ __global__ void k_unshard_all(rt_shard_geom g, uint32_t total_slots, const doubl
     }
 }
 
+// ... and for shards that were tone-mapped where they were rendered (rt_render_multi_rgb8)
+__global__ void k_unshard_all_rgb8(rt_shard_geom g, uint32_t total_slots, const uint8_t *__restrict__ shards_rgb8, uint8_t *__restrict__ full_rgb8)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_slots) return;
+    const uint32_t gt = i / g.tile_px, j = i - gt * g.tile_px;
+    const uint32_t base = g.n_tiles / g.shard_count, rem = g.n_tiles % g.shard_count;
+    uint32_t rank, local_tile;
+    if (gt < rem * (base + 1u)) {
+        rank = gt / (base + 1u);
+        local_tile = gt - rank * (base + 1u);
+    } else {
+        const uint32_t r = gt - rem * (base + 1u);
+        rank = rem + r / base;
+        local_tile = r % base;
+    }
+    uint32_t x, y;
+    if (rt_shard_decode(&g, rank, local_tile * g.tile_px + j, &x, &y)) {
+        const size_t p = (size_t)y * g.width + x;
+        full_rgb8[p * 3 + 0] = shards_rgb8[(size_t)i * 3 + 0];
+        full_rgb8[p * 3 + 1] = shards_rgb8[(size_t)i * 3 + 1];
+        full_rgb8[p * 3 + 2] = shards_rgb8[(size_t)i * 3 + 2];
+    }
+}
+
 // rt_trace_rays: the caller's interleaved rays (xyz, xyz, ...) into queue entries 0 .. n-1, ray i keyed as pixel i
 __global__ void k_rays_in(uint32_t n, const double *__restrict__ origins, const double *__restrict__ directions, RayQueue q)
 {

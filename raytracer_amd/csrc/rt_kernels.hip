@@ -1544,8 +1544,14 @@ static int render_multi_impl(rt_scene *const *scenes, uint32_t n_devices, const 
         }
     }
     if (rgb8) {
-        HIP_TRY(hipSetDevice(root->device));
-        if ((rc = ensure_snapshot(root, n_px))) return rc;
+        // the picture: every GPU tone-maps its own tiles where they lie (the pixel math of main.rs:201-217 is per pixel,
+        // so it commutes with the gather) and 3 bytes per slot cross the links instead of 24.  The root's byte buffer:
+        // [row-major image | region of shard 0 | region of shard 1 | ...]; a peer on another GPU tone-maps into its own.
+        for (uint32_t k = 0; k < n_devices; ++k) {
+            HIP_TRY(hipSetDevice(scenes[k]->device));
+            const size_t need8 = k == 0 ? n_px + total_slots : (scenes[k]->device == root->device ? 0 : n_slots[k]);
+            if (need8 && (rc = ensure_snapshot(scenes[k], need8))) return rc;
+        }
     }
     auto region_rgb = [&](uint32_t k) { return root->out_rgb + (n_px + first_slot[k]) * 3; };
     auto region_ids = [&](uint32_t k) { return primary_ids ? root->out_ids + n_px + first_slot[k] : (int32_t *)nullptr; };
@@ -1565,11 +1571,17 @@ static int render_multi_impl(rt_scene *const *scenes, uint32_t n_devices, const 
         if (r == RT_OK && n_slots[k] && !sh.error.load()) {
             // the one exchange step, this GPU's half: push the shard into its region of the root's buffer
             hipError_t e = hipSuccess;
-            if (!is_local(k)) {
+            if (rgb8) {
+                uint8_t *region8 = root->snap_d + (n_px + first_slot[k]) * 3;
+                uint8_t *mine8 = is_local(k) ? region8 : s->snap_d;
+                r = rt_tonemap_device(shard_rgb(k), n_slots[k], (double)st[k].strata + 1.0, mine8, s->multi_stream);
+                if (r == RT_OK && !is_local(k))
+                    e = hipMemcpyPeerAsync(region8, root->device, mine8, s->device, n_slots[k] * 3, s->multi_stream);
+            } else if (!is_local(k)) {
                 e = hipMemcpyPeerAsync(region_rgb(k), root->device, s->out_rgb, s->device, n_slots[k] * 3 * sizeof(double), s->multi_stream);
-                if (e == hipSuccess && primary_ids)
-                    e = hipMemcpyPeerAsync(region_ids(k), root->device, s->out_ids, s->device, n_slots[k] * sizeof(int32_t), s->multi_stream);
             }
+            if (e == hipSuccess && primary_ids && !is_local(k))
+                e = hipMemcpyPeerAsync(region_ids(k), root->device, s->out_ids, s->device, n_slots[k] * sizeof(int32_t), s->multi_stream);
             if (e == hipSuccess) e = hipEventRecord(s->multi_done, s->multi_stream);
             if (e != hipSuccess) {
                 r = RT_ERR_DEVICE;
@@ -1603,14 +1615,19 @@ static int render_multi_impl(rt_scene *const *scenes, uint32_t n_devices, const 
         for (uint32_t k = 1; k < n_devices; ++k)
             if (n_slots[k]) HIP_TRY(hipStreamWaitEvent(s0, scenes[k]->multi_done, 0));
         const rt_shard_geom g = rt_shard_geom_make(sh.opts.width, sh.opts.height, sh.opts.tile_size, n_devices);
-        hipLaunchKernelGGL(k_unshard_all, dim3((uint32_t)((total_slots + 255) / 256)), dim3(256), 0, s0, g, (uint32_t)total_slots,
-                           root->out_rgb + n_px * 3, root->out_rgb, primary_ids ? root->out_ids + n_px : nullptr,
-                           primary_ids ? root->out_ids : nullptr);
-        HIP_TRY(hipGetLastError());
-        uint32_t strata_done = 0;
-        for (uint32_t k = 0; k < n_devices; ++k) strata_done = std::max(strata_done, st[k].strata);
         if (rgb8) {
-            if ((rc = rt_tonemap_device(root->out_rgb, n_px, (double)strata_done + 1.0, root->snap_d, s0))) return rc;
+            hipLaunchKernelGGL(k_unshard_all_rgb8, dim3((uint32_t)((total_slots + 255) / 256)), dim3(256), 0, s0, g, (uint32_t)total_slots,
+                               root->snap_d + n_px * 3, root->snap_d);
+            if (primary_ids)
+                hipLaunchKernelGGL(k_unshard_all, dim3((uint32_t)((total_slots + 255) / 256)), dim3(256), 0, s0, g, (uint32_t)total_slots,
+                                   (const double *)nullptr, (double *)nullptr, root->out_ids + n_px, root->out_ids);
+        } else {
+            hipLaunchKernelGGL(k_unshard_all, dim3((uint32_t)((total_slots + 255) / 256)), dim3(256), 0, s0, g, (uint32_t)total_slots,
+                               root->out_rgb + n_px * 3, root->out_rgb, primary_ids ? root->out_ids + n_px : nullptr,
+                               primary_ids ? root->out_ids : nullptr);
+        }
+        HIP_TRY(hipGetLastError());
+        if (rgb8) {
             HIP_TRY(hipMemcpyAsync(rgb8, root->snap_d, n_px * 3, hipMemcpyDeviceToHost, s0));
         } else {
             HIP_TRY(hipMemcpyAsync(rgb_sum, root->out_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost, s0));

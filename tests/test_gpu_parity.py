@@ -743,6 +743,11 @@ def test_render_multi_equals_whole_and_reports_progress(rt, tmp_path):
     # the same frame as an image: tone-mapped on the first GPU by strata + 1 (main.rs:201-222), 3 bytes per pixel out
     img8, ids8, st8 = rt.render_multi(o, devs[:3], rgb8=True)
     assert np.array_equal(img8, rt.tonemap(whole, 10)) and np.array_equal(ids8, wids) and st8.rays == wst.rays
+    for n in (1, 2, 8):  # (every GPU tone-maps its own tiles before the push; progress snapshots use the same byte buffers)
+        shots8 = []
+        img8n, ids8n, _ = rt.render_multi(o, devs[:n], rt.DeviceProgress(on_snapshot=lambda d, t, img: shots8.append(d) and None, min_interval=0.0),
+                                          rgb8=True)
+        assert np.array_equal(img8n, img8) and np.array_equal(ids8n, wids) and shots8 == list(range(1, 9)), n
     one8, oid8, ost8 = devs[0].render_rgb8(o, want_ids=True)
     assert np.array_equal(one8, img8) and np.array_equal(oid8, wids) and ost8.rays == wst.rays
     # page-locked buffers the DeviceScene keeps: the same frame, the same arrays handed out again
