@@ -436,28 +436,87 @@ RT_DEV void leaf_surface(const DevLeaf &L, const LeafRay &ry, d3 q, uint32_t tag
 }
 
 // ---------------------------------------------------------------------------
-// Interval lists: end points (t, tag), 2 per interval.  The lists of a ray live in scratch memory (they are indexed
-// by run-time values), and a launch's waves together hold waves x 64 x (lists x bytes) of it: with 12 intervals per
-// list and 10 lists that is 2.9 KB per lane and 600 MB over the chip - far beyond the caches, so every list access
-// went to HBM (room.scene 4K: 6.0 GB of HBM traffic per k_intersect launch against 1.1 GB algorithmic).  The capacity
-// is a template parameter: scenes whose CSG trees provably never hold more than DEV_SMALL_INTERVALS intervals in a
-// list nor more than DEV_SMALL_STACK lists at once (every scene the reference ships; the flattener bounds both from
-// the tree, rt_flatten.cpp interval_need / stack_need) can run kernels instantiated with those, 864 bytes per lane
-// (-DRT_CSG_SMALL_KERNELS=1).  Measured, the capacity is not what costs: only the entries a ray stores travel, and
-// those are the same - see csg_eval, which stores each list once, and rt_kernels.hip for the numbers.
+// Interval lists: end points (t, tag), 2 per interval.  In the general kernels the lists of a ray live in scratch
+// memory (they are indexed by run-time values), and a launch's waves together hold waves x 64 x (lists x bytes) of it:
+// with 12 intervals per list and 9 lists that is 2.9 KB per lane and 600 MB over the chip - far beyond the caches, so
+// every list access goes to HBM (room.scene 4K: 6.0 GB of HBM traffic per k_intersect launch against 1.1 GB
+// algorithmic before csg_eval stored each list once, 4.0 GB after).  A smaller capacity changes nothing there: only the
+// entries a ray stores travel (kernels with 4 intervals x 5 lists measured the same, round 3).
 template <int MAXI>
 struct IvListT {
     static constexpr int CAP = MAXI;
     double t[2 * MAXI];
     uint32_t tag[2 * MAXI];
     int n; // intervals
+    RT_DEV static constexpr int cap() { return MAXI; }
 };
 typedef IvListT<DEV_MAX_INTERVALS> IvList;
+
+// The same lists in LDS, for scenes whose trees are small enough that every lane of the workgroups a CU holds gets
+// room for all of them (the flattener's bounds: `cap` intervals per list, `n_lists` lists at once; rt_kernels.hip
+// decides).  Scratch memory has the capacity of HBM and, with thousands of waves in flight, its latency; LDS is a
+// hundred cycles away.  Entry e of list l of thread x sits at t[(l * 2 cap + e) * STRIDE + x] (STRIDE = threads per
+// workgroup): the lanes of a wave touch neighbouring words whatever entry each of them is at.  The interval counts
+// stay in a register, four bits per list.  An LdsList is a view (three pointers and a shift) with the member names of
+// IvListT, so the interval algebra below is written once.
+template <int STRIDE>
+struct LdsList {
+    struct TArr {
+        double *b;
+        RT_DEV double &operator[](int i) const { return b[i * STRIDE]; }
+    };
+    struct GArr {
+        uint32_t *b;
+        RT_DEV uint32_t &operator[](int i) const { return b[i * STRIDE]; }
+    };
+    struct NRef {
+        uint32_t *w;
+        uint32_t sh;
+        RT_DEV operator int() const { return (int)((*w >> sh) & 15u); }
+        RT_DEV NRef &operator=(int v)
+        {
+            *w = (*w & ~(15u << sh)) | ((uint32_t)v << sh);
+            return *this;
+        }
+        RT_DEV NRef &operator=(const NRef &o) { return *this = (int)o; }
+        RT_DEV int operator++(int)
+        {
+            const int v = *this;
+            *this = v + 1;
+            return v;
+        }
+    };
+    TArr t;
+    GArr tag;
+    NRef n;
+    int cap_;
+    RT_DEV int cap() const { return cap_; }
+};
+
+// all lists of one thread: stack[l] is list l
+template <int STRIDE>
+struct LdsLists {
+    double *t;       // this thread's column of the end points
+    uint32_t *tag;   // ... and of the tags
+    int cap_;        // intervals per list (at most 15)
+    int n_lists;     // at most 8
+    uint32_t counts; // intervals in list l: bits 4l .. 4l + 3
+    RT_DEV LdsList<STRIDE> operator[](int l)
+    {
+        LdsList<STRIDE> v;
+        v.t.b = t + l * 2 * cap_ * STRIDE;
+        v.tag.b = tag + l * 2 * cap_ * STRIDE;
+        v.n.w = &counts;
+        v.n.sh = 4u * (uint32_t)l;
+        v.cap_ = cap_;
+        return v;
+    }
+};
 
 template <class LST>
 RT_DEV void iv_push(LST &l, double t0, uint32_t g0, double t1, uint32_t g1, Guards &gd)
 {
-    if (l.n >= LST::CAP) {
+    if (l.n >= l.cap()) {
         gd.overflow++;
         return;
     }
@@ -472,7 +531,7 @@ template <class LST>
 RT_DEV void iv_copy(LST &dst, const LST &src)
 {
     dst.n = src.n;
-    for (int i = 0; i < 2 * LST::CAP; ++i) {
+    for (int i = 0; i < 2 * src.cap(); ++i) {
         if (i >= 2 * src.n) break;
         dst.t[i] = src.t[i];
         dst.tag[i] = src.tag[i];
@@ -517,7 +576,7 @@ RT_CSG_FN bool csg_apply(int op, const LST &A, const LST &B, LST &out, Guards &g
     int n_out = 0;
 #define PUSH(T0, G0, T1, G1)                                                                                           \
     do {                                                                                                               \
-        if (n_out >= LST::CAP) {                                                                                       \
+        if (n_out >= out.cap()) {                                                                                      \
             gd.overflow++;                                                                                             \
         } else {                                                                                                       \
             out.t[2 * n_out] = (T0);                                                                                   \
@@ -572,7 +631,7 @@ RT_CSG_FN bool csg_apply(int op, const LST &A, const LST &B, LST &out, Guards &g
     } while (0)
     int guard_iter = 0;
     while (ia < A.n && ib < B.n) {
-        if (++guard_iter > 8 * LST::CAP) break; // cannot happen; keeps the loop provably finite
+        if (++guard_iter > 8 * out.cap()) break; // cannot happen; keeps the loop provably finite
         if (op == DEV_OP_UNION) {
             if (ae < bs) {
                 PUSH(as, asg, ae, aeg);
@@ -671,6 +730,10 @@ RT_DEV void leaf_world_intervals(const DevLeaf &L, uint32_t rel, d3 ow, d3 dw, L
     double t[4];
     uint32_t sub[4];
     int n = leaf_ends<TORUS>(L, ry, t, sub, gd);
+    if (n > 2 * out.cap()) { // cannot happen: the flattener's bound counts two intervals for a torus, one for the others
+        gd.overflow++;
+        n = 2 * out.cap();
+    }
     out.n = n >> 1;
     for (int i = 0; i < 4; ++i) {
         if (i >= n) break;
@@ -695,29 +758,32 @@ RT_DEV double skip_scale(const DevLeaf &Q, d3 dw)
 // of it list stores).  So nothing is stored twice: an operation writes its result into the one list that is free
 // (never an operand) and the stack entries are renamed - `perm` holds, four bits per stack position, which list a
 // position uses - instead of copied; the result is read where it lies.
-template <bool TORUS, int STK, class LST>
-RT_CSG_FN int csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, LST *stack, Guards &gd)
+// `stack`: an array of IvListT (scratch memory) or an LdsLists; `stk` + 1 lists.
+template <bool TORUS, class STACK>
+RT_CSG_FN int csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, STACK &stack, const int stk, Guards &gd)
 {
-    static_assert(STK + 1 <= 16, "four bits per stack position");
-    uint64_t perm = 0xFEDCBA9876543210ull; // position k uses list (perm >> 4k) & 15
-    int free_list = STK;
+    uint64_t perm = 0xFEDCBA9876543210ull; // position k uses list (perm >> 4k) & 15 (stk + 1 <= 16)
+    int free_list = stk;
     int sp = 0;
 #define CSG_LIST(POS) ((int)((perm >> (4 * (POS))) & 15ull))
     for (int pc = 0; pc < ob.prog_len; ++pc) {
         int word = sc.prog[ob.prog0 + pc];
         int op = (word >> 24) & 0x7F;
         if (op == DEV_OP_LEAF) {
-            if (sp >= STK) {
+            if (sp >= stk) {
                 gd.overflow++;
                 return -1;
             }
             uint32_t rel = (uint32_t)(word & 0xFFFFFF);
-            leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0 + rel], rel, ow, dw, stack[CSG_LIST(sp)], gd);
+            auto &&dst = stack[CSG_LIST(sp)];
+            leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0 + rel], rel, ow, dw, dst, gd);
             ++sp;
         } else {
             if (sp < 2) return -1;
             const int la = CSG_LIST(sp - 2), lb = CSG_LIST(sp - 1);
-            const int na = stack[la].n, nb = stack[lb].n;
+            auto &&A = stack[la];
+            auto &&B = stack[lb];
+            const int na = A.n, nb = B.n;
             const bool one_missed = na == 0 || nb == 0;
             // an operand missed: the result is one of the operands as it stands (csg_apply's own first lines, csg.rs:
             // 33-38,137-139,216-221) - taken by renaming, not by copying
@@ -728,14 +794,17 @@ RT_CSG_FN int csg_eval(const DevScene &sc, const DevObject &ob, d3 ow, d3 dw, LS
                 lr = na == 0 ? la : (nb == 0 ? lb : free_list);
             else
                 lr = one_missed ? la : free_list;
-            if (lr == free_list && !csg_apply(op, stack[la], stack[lb], stack[free_list], gd)) return -1;
-            LST &out = stack[lr];
+            if (lr == free_list) {
+                auto &&R = stack[free_list];
+                if (!csg_apply(op, A, B, R, gd)) return -1;
+            }
+            auto &&out = stack[lr];
             if ((word & DEV_PROG_SKIP) && one_missed && out.n > 0) {
                 // csg.rs:33-38,216-221: the surviving operand's end points keep this node's space
                 const DevLeaf &Q = sc.leaves[ob.leaf0 + (word & 0xFFFF)];
                 const double f = skip_scale(Q, dw);
                 const uint32_t bit = 1u << (TAG_SKIP_SHIFT + Q.skip_ord - 1);
-                for (int i = 0; i < 2 * LST::CAP; ++i) {
+                for (int i = 0; i < 2 * out.cap(); ++i) {
                     if (i >= 2 * out.n) break;
                     out.t[i] *= f;
                     out.tag[i] |= bit;

@@ -192,6 +192,7 @@ struct DevScene {
     uint32_t n_jobs;
     uint32_t n_leaves, n_meshes, n_materials, n_textures;
     uint32_t starts_in_lds; // k_mesh keeps cell_start in LDS too (they fit beside the other grid tables)
+    uint32_t lds_list_cap, lds_list_n; // interval lists in LDS (k_intersect<.., LL = true>): intervals per list, lists per ray; 0: none
     double background[3];
     double cam_fov_factor;
     double cam_c2w[16];
@@ -200,8 +201,8 @@ struct DevScene {
 #define DEV_MAX_LEAVES_PER_OBJECT 256
 #define DEV_MAX_INTERVALS 12  // per list (beyond: counted in rt_stats.interval_overflow, the object is a miss for that ray)
 #define DEV_CSG_STACK 8       // lists alive at once: right-nested operations need one each, checked at rt_scene_create
-#define DEV_SMALL_INTERVALS 4 // the same two limits of the kernels instantiated for scenes that provably stay within them
-#define DEV_SMALL_STACK 4     // (rt_dev_shapes.h, IvListT): a fifth of the scratch memory per ray
+#define DEV_LDS_LIST_MAX_INTERVALS 15 // limits of the interval lists kept in LDS (LdsLists, rt_dev_shapes.h: four bits per count,
+#define DEV_LDS_LIST_MAX_LISTS 8      // a 32-bit word of counts); what fits is decided per scene from the flattener's bounds
 #define DEV_GRID_MAX_WORDS 2048 // occupancy words of all meshes together: 16 KB of LDS with their ranks, 32 KB of distances
 #define DEV_GRID_MAX_STARTS 6144 // cell_start entries kept in LDS (24 KB); beyond that they are read from memory
 #define DEV_GRID_MAX_AXIS 255

@@ -61,7 +61,11 @@ struct HitBuf {
 #endif
 // k_tail without CSG / fog / torus code (the bench scene's variant): waves per SIMD it is compiled for
 #define RT_TAIL_OCC __attribute__((amdgpu_waves_per_eu((CSG || MEDIUM || TORUS) ? 1 : RT_TAIL_WAVES)))
-#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(TORUS ? RT_TORUS_WAVES : (MEDIUM ? RT_MEDIUM_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES)))))
+// ... and the variants with their interval lists in LDS at RT_LL_WAVES: the lists of two workgroups fill a CU's LDS
+#ifndef RT_LL_WAVES
+#define RT_LL_WAVES 2
+#endif
+#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(LL ? RT_LL_WAVES : (TORUS ? RT_TORUS_WAVES : (MEDIUM ? RT_MEDIUM_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES))))))
 
 struct PassParams {
     uint64_t seed;

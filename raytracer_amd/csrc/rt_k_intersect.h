@@ -27,7 +27,7 @@ RT_DEV Candidate pick_from_list(const LST &l, int mode)
         c.ok = true;
         return c;
     }
-    for (int i = 0; i < 2 * LST::CAP; ++i) {
+    for (int i = 0; i < 2 * l.cap(); ++i) {
         if (i >= 2 * l.n) break;
         if (!(l.t[i] < 0.0)) {
             c.t = l.t[i];
@@ -75,19 +75,26 @@ RT_DEV Candidate eval_leaf_object(const DevScene &sc, const DevObject &ob, d3 o,
     return c;
 }
 
-// SMALL: the scene's lists fit DEV_SMALL_INTERVALS / DEV_SMALL_STACK (IvListT, rt_dev_shapes.h)
-template <bool TORUS, bool SMALL>
-RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd)
+// LL: the ray's interval lists are in LDS (`ll`: LdsLists, rt_dev_shapes.h), not in scratch memory
+template <bool TORUS, bool LL, class LISTS>
+RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 o, d3 d, Guards &gd, LISTS &ll)
 {
     Candidate c;
     c.ok = false;
     c.t = 0.0;
     c.aux = 0u;
-    constexpr int STK = SMALL ? DEV_SMALL_STACK : DEV_CSG_STACK;
-    IvListT<SMALL ? DEV_SMALL_INTERVALS : DEV_MAX_INTERVALS> lists[STK + 1];
-    const int r = csg_eval<TORUS, STK>(sc, ob, o, d, lists, gd);
-    if (r < 0) return c;
-    return pick_from_list(lists[r], ob.mode);
+    if constexpr (LL) {
+        ll.counts = 0u;
+        const int r = csg_eval<TORUS>(sc, ob, o, d, ll, ll.n_lists - 1, gd);
+        if (r < 0) return c;
+        auto &&res = ll[r];
+        return pick_from_list(res, ob.mode);
+    } else {
+        IvListT<DEV_MAX_INTERVALS> lists[DEV_CSG_STACK + 1];
+        const int r = csg_eval<TORUS>(sc, ob, o, d, lists, DEV_CSG_STACK, gd);
+        if (r < 0) return c;
+        return pick_from_list(lists[r], ob.mode);
+    }
 }
 
 // Does the ray need the walk through a mesh of this object?  Only a conservative answer is wanted here (k_mesh
@@ -112,10 +119,10 @@ RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3
     return any;
 }
 
-// HomogenousMedium::intersect (homogenous_medium.rs:29-57)
-template <bool CSG, bool TORUS, bool SMALL>
-RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
-                                                     d3 d, const PassParams &pp, uint32_t pixel, Guards &gd)
+// HomogenousMedium::intersect (homogenous_medium.rs:29-57) on the lists `stack` (stk + 1 of them)
+template <bool CSG, bool TORUS, class STACK>
+RT_CSG_FN Candidate medium_on_lists(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o, d3 d, const PassParams &pp,
+                                    uint32_t pixel, Guards &gd, STACK &stack, const int stk)
 {
     Candidate c;
     c.ok = false;
@@ -125,24 +132,23 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
     LeafRay ry = to_leaf(F, o, d);
     // a world-space distance along the ray is `scale` times longer in the medium's space
     double scale = F.identity ? 1.0 : len3(xf_dir(F.W, d));
-    constexpr int STK = SMALL ? DEV_SMALL_STACK : DEV_CSG_STACK;
-    typedef IvListT<SMALL ? DEV_SMALL_INTERVALS : DEV_MAX_INTERVALS> LST;
-    LST lists[CSG ? STK + 1 : 1];
     int r = 0;
     if (ob.prog_len == 0) {
-        lists[0].n = 0;
-        leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, lists[0], gd);
+        auto &&l0 = stack[0];
+        l0.n = 0;
+        leaf_world_intervals<TORUS>(sc.leaves[ob.leaf0], 0u, o, d, l0, gd);
     } else {
-        r = CSG ? csg_eval<TORUS, STK>(sc, ob, o, d, lists, gd) : -1;
+        r = CSG ? csg_eval<TORUS>(sc, ob, o, d, stack, stk, gd) : -1;
         if (r < 0) return c;
     }
-    const LST &res = lists[r];
-    if (res.n == 0) return c;
+    auto &&res = stack[r];
+    const int res_n = res.n;
+    if (res_n == 0) return c;
     int first = 0;
-    while (first < res.n && res.t[2 * first] < 0.0 && res.t[2 * first + 1] < 0.0) ++first; // skip_negative_intervals
+    while (first < res_n && res.t[2 * first] < 0.0 && res.t[2 * first + 1] < 0.0) ++first; // skip_negative_intervals
     double dlen = len3(ry.d);
     uint32_t k = 0;
-    for (int i = first; i < res.n; ++i) {
+    for (int i = first; i < res_n; ++i) {
         double at = fmax(res.t[2 * i] * scale, 0.0), bt = res.t[2 * i + 1] * scale;
         double distance = len3(ry.d * (bt - at));
         rt_rng_block blk = rt_rng_draw(pp.seed, pixel, pp.stratum, pp.depth, RT_RNG_SITE_MEDIUM + k, obj_index);
@@ -158,6 +164,19 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
     return c;
 }
 
+template <bool CSG, bool TORUS, bool LL, class LISTS>
+RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, uint32_t obj_index, d3 o,
+                                                     d3 d, const PassParams &pp, uint32_t pixel, Guards &gd, LISTS &ll)
+{
+    if constexpr (LL) {
+        ll.counts = 0u;
+        return medium_on_lists<CSG, TORUS>(sc, ob, obj_index, o, d, pp, pixel, gd, ll, ll.n_lists - 1);
+    } else {
+        IvListT<DEV_MAX_INTERVALS> lists[CSG ? DEV_CSG_STACK + 1 : 1];
+        return medium_on_lists<CSG, TORUS>(sc, ob, obj_index, o, d, pp, pixel, gd, lists, CSG ? DEV_CSG_STACK : 0);
+    }
+}
+
 // Pass 1 of the nearest-hit search: every object except the triangle work.
 // A ray that passes the bounding box of a mesh object is appended to
 // `mesh_queue`; k_mesh then walks the mesh grids and merges its result into the
@@ -165,8 +184,10 @@ RT_CSG_FN Candidate eval_medium_object(const DevScene &sc, const DevObject &ob, 
 // scene does not need.
 // Ray::trace (system.rs:122-133) over every object except the triangle work; returns whether
 // the ray still has to visit a mesh.
-template <bool CSG, bool MEDIUM, bool TORUS, bool SMALL = false>
-RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, const PassParams &pp, HitRec &h, Guards &gd)
+// LL: the interval lists are in LDS (`ll`), else `ll` is a NoLdsLists and the lists are in scratch memory.
+struct NoLdsLists {};
+template <bool CSG, bool MEDIUM, bool TORUS, bool LL, class LISTS>
+RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, const PassParams &pp, HitRec &h, Guards &gd, LISTS &ll)
 {
     bool wants_mesh = false;
     // first object wins ties, t must be < f64::MAX
@@ -198,11 +219,11 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
         switch (ob.kind) {
         case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
         case DO_CSG:
-            if (CSG) c = eval_csg_object<TORUS, SMALL>(sc, ob, o, d, gd);
+            if (CSG) c = eval_csg_object<TORUS, LL>(sc, ob, o, d, gd, ll);
             break;
         case DO_MESH: wants_mesh = true; break; // decided below, once the other objects' nearest hit is known
         default:
-            if (MEDIUM) c = eval_medium_object<CSG, TORUS, SMALL>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd);
+            if (MEDIUM) c = eval_medium_object<CSG, TORUS, LL>(sc, ob, (uint32_t)k, o, d, pp, pixel, gd, ll);
             break;
         }
         // Object::intersect keeps t >= 0 (object.rs:50-54)
@@ -274,6 +295,14 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
     return wants_mesh;
 }
 
+// ... with the lists in scratch memory
+template <bool CSG, bool MEDIUM, bool TORUS>
+RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, const PassParams &pp, HitRec &h, Guards &gd)
+{
+    NoLdsLists none;
+    return intersect_analytic<CSG, MEDIUM, TORUS, false>(sc, o, d, pixel, pp, h, gd, none);
+}
+
 // One path segment per ray: nearest hit over the analytic objects (Ray::trace, system.rs:122-133), then
 //  - a ray that still has to visit a mesh is appended to the mesh record queue (`mq` + `mqh`, indexed by queue
 //    position): origin, direction, attenuation so far, pixel keys and the hit found so far.  k_mesh reads the
@@ -283,7 +312,9 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 //    path's colour is added to its pixel.
 // !FUSED (rt_trace_rays): no shading; the hit record of every ray i goes to `hit[i]`, and mesh records carry i
 // in their slot field so that k_copy_mesh_hits can put the merged hit back.
-template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED, bool SMALL>
+// LL: the interval lists of the CSG / fog variants in LDS behind the scene tables (sc_mem.lds_list_cap intervals per
+// list, sc_mem.lds_list_n lists per ray: the launch code has checked that two workgroups per CU find room)
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED, bool LL>
 __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
@@ -294,6 +325,15 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     __shared__ uint32_t append_lds[2 * (RT_ISECT_BLOCK / 64 + 1)];
+    LdsLists<RT_ISECT_BLOCK> ll;
+    if (LL) {
+        unsigned char *lists_lds = reinterpret_cast<unsigned char *>(scene_lds) + ((scene_lds_bytes(sc_mem) + 15u) & ~15u);
+        ll.cap_ = (int)sc_mem.lds_list_cap;
+        ll.n_lists = (int)sc_mem.lds_list_n;
+        ll.t = reinterpret_cast<double *>(lists_lds) + threadIdx.x;
+        ll.tag = reinterpret_cast<uint32_t *>(lists_lds + (size_t)ll.n_lists * 2 * ll.cap_ * RT_ISECT_BLOCK * 8) + threadIdx.x;
+        ll.counts = 0u;
+    }
     const uint32_t count = *count_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
@@ -319,7 +359,11 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
                     thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
                 }
             }
-            wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS, SMALL>(sc, o, d, pixel, pp, h, gd);
+            if constexpr (LL) {
+                wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS, true>(sc, o, d, pixel, pp, h, gd, ll);
+            } else {
+                wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
+            }
             if (primary_ids) primary_ids[FUSED ? slot : ray_slot(q, i)] = h.obj;
             if (!FUSED) {
                 hit.t[i] = h.t;

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
 // the meshes by brute force across the 64 lanes, the material - with no launch per bounce.
 // The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
-template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool SMALL>
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS>
 __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
                                                     uint32_t *lane_totals)
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
         PassParams p = pp;
         for (;;) {
             HitRec h;
-            bool wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS, SMALL>(sc, o, d, pixel, p, h, gd);
+            bool wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, p, h, gd);
             if (has_mesh && wants_mesh) {
                 int best_obj = h.obj;
                 double best_t = best_obj >= 0 ? h.t : DBL_MAX;

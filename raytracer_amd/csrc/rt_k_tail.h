@@ -67,7 +67,7 @@ RT_DEV double bcast_f64(double v, int lane)
 RT_DEV d3 bcast_d3(d3 v, int lane) { return mk3(bcast_f64(v.x, lane), bcast_f64(v.y, lane), bcast_f64(v.z, lane)); }
 
 // dynamic LDS: [scene tables (scene_lds_bytes, 16-byte aligned) | job record | grid tables]
-template <bool CSG, bool MEDIUM, bool TORUS, bool SMALL>
+template <bool CSG, bool MEDIUM, bool TORUS>
 __global__ void __launch_bounds__(RT_TAILG_LANES) __attribute__((amdgpu_waves_per_eu(RT_TAILG_WAVES, RT_TAILG_WAVES)))
 k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, PassParams pp, uint32_t *guards_out,
             uint32_t *lane_totals)
@@ -150,7 +150,7 @@ k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, Pas
             h.u = h.v = 0.0;
             h.obj = -1;
             bool wants = false;
-            if (alive) wants = intersect_analytic<CSG, MEDIUM, TORUS, SMALL>(sc, wo, wd, pixel, p, h, gd);
+            if (alive) wants = intersect_analytic<CSG, MEDIUM, TORUS>(sc, wo, wd, pixel, p, h, gd);
             const uint64_t want_mask = __ballot(wants);
             TG_MARK(0);
 #ifdef RT_TAILG_PROF

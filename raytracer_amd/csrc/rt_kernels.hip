@@ -135,7 +135,8 @@ struct rt_scene {
     void *ws = nullptr;
     Workspace own;
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
-    bool csg_small = false; // every interval list of the scene fits DEV_SMALL_INTERVALS / DEV_SMALL_STACK: the kernels with short lists
+    bool ll_attr_set = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this scene's LL variant on its device
+    uint32_t isect_ll_bytes = 0; // dynamic LDS of k_intersect<.., LL = true> (scene tables + every lane's interval lists); 0: the lists stay in scratch memory
     uint64_t n_mesh_tris = 0;
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
     bool any_grid = false, any_kd = false; // (object, mesh) jobs walked through grids / through kd-trees
@@ -381,12 +382,28 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
     for (const DevLeaf &L : flat.leaves)
         if (L.kind == DL_TORUS) s->has_torus = true;
     for (const DevMesh &m : flat.meshes) s->n_mesh_tris += m.n_tris;
-    {
-        const char *e = getenv("RT_CSG_SMALL"); // "0": always the kernels with full-size lists (measurements, tests)
-        s->csg_small = (s->has_csg || s->has_medium) && flat.max_intervals <= DEV_SMALL_INTERVALS && flat.max_stack <= DEV_SMALL_STACK &&
-                       !(e && !strcmp(e, "0"));
-        RT_TRACE("interval lists: at most %d intervals, %d lists at once -> %s kernels", flat.max_intervals, flat.max_stack,
-                 s->csg_small ? "short-list" : "full-size");
+    s->dev.lds_list_cap = s->dev.lds_list_n = 0u;
+    if (s->has_csg || s->has_medium) {
+        // Interval lists in LDS (LdsLists, rt_dev_shapes.h) when the lists of two workgroups and their scene tables fit
+        // a CU: `cap` intervals per list and `lists` lists per ray are the flattener's bounds over all the scene's
+        // trees (a program needs one list per operand alive and one for a result; a fog boundary that is a single
+        // primitive needs one).  12 bytes per end point and lane.
+        int lds_limit = 0;
+        if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device) != hipSuccess || lds_limit <= 0)
+            lds_limit = 65536;
+        const uint32_t cap = (uint32_t)std::max(flat.max_intervals, 1), lists = s->has_csg ? (uint32_t)flat.max_stack + 1u : 1u;
+        const uint64_t want = (uint64_t)((scene_lds_bytes(s->dev) + 15u) & ~15u) + (uint64_t)lists * 2u * cap * RT_ISECT_BLOCK * 12u;
+        const char *e = getenv("RT_LDS_LISTS"); // "0": the lists stay in scratch memory (measurements, tests)
+        const bool off = e && !strcmp(e, "0");
+        // (the kernel's static LDS - the append's words - and the allocation granularity take a little more: 1 KB each)
+        if (!off && scene_lds_bytes(s->dev) != 0u && cap <= DEV_LDS_LIST_MAX_INTERVALS && lists <= DEV_LDS_LIST_MAX_LISTS &&
+            want + 1024u <= (uint64_t)lds_limit / RT_LL_WAVES) {
+            s->isect_ll_bytes = (uint32_t)want;
+            s->dev.lds_list_cap = cap;
+            s->dev.lds_list_n = lists;
+        }
+        RT_TRACE("interval lists: at most %d intervals, %d lists at once -> %s (%u bytes of LDS per k_intersect workgroup)",
+                 flat.max_intervals, flat.max_stack, s->isect_ll_bytes ? "in LDS" : "in scratch memory", s->isect_ll_bytes);
     }
     for (int k = 0; k < 3; ++k) s->dev.background[k] = flat.background[k];
     s->dev.cam_fov_factor = flat.cam_fov_factor;
@@ -472,14 +489,6 @@ static int check_options(const rt_options *o)
     return RT_OK;
 }
 
-// Kernels instantiated with short interval lists (IvListT<DEV_SMALL_INTERVALS>, 864 instead of 3200 bytes of scratch
-// memory per lane) for scenes whose trees never need more: built only with -DRT_CSG_SMALL_KERNELS=1.  Measured on
-// MI355X (room 4K, csg 4K, fog_light 8K x 16): no difference - 3842 / 3675 / 8265 Mrays/s with them, 3842 / 3664 / 8241
-// without: a list costs the entries a ray stores into it, not its capacity (rt_dev_shapes.h, csg_eval).  They double
-// the build time of the CSG variants, so the default build leaves them out.
-#ifndef RT_CSG_SMALL_KERNELS
-#define RT_CSG_SMALL_KERNELS 0
-#endif
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
 // One depth level for the `count_ptr[0]` rays of `q`: k_intersect (nearest analytic hit; rays with no mesh to
@@ -501,23 +510,27 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     // (only long queues: short ones go to k_mesh_brute, which writes the hit record itself)
     const bool one = s->has_mesh && s->any_grid && s->mesh_pool_lds_bytes != 0u &&
                      (uint64_t)live * s->n_mesh_tris > (uint64_t)RT_BRUTE_MAX_TESTS;
-#define LAUNCH_IS(C, M, T, L, F, S)                                                                                    \
-    hipLaunchKernelGGL((k_intersect<C, M, T, L, F, S>), grid, block, scene_lds_bytes(s->dev), st, s->dev, q, count_ptr, pp, ids,      \
-                       w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, one ? w.mres_tri : nullptr)
-// the short-list instantiation exists for the variants that hold interval lists (CSG programs, fog boundaries)
+#define LAUNCH_IS(C, M, T, L, F, LL)                                                                                   \
+    hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
+                       count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work,    \
+                       one ? w.mres_tri : nullptr)
+// the variants that hold interval lists (CSG programs, fog boundaries) exist a second time with the lists in LDS, for
+// the wavefront passes (fused) of scenes whose lists fit there
 #define LAUNCH_I(C, M, T, L)                                                                                           \
     do {                                                                                                               \
-        constexpr bool lists_ = (C || M) && L && RT_CSG_SMALL_KERNELS;                                                 \
+        constexpr bool lists_ = (C || M) && L;                                                                         \
         if (fused) {                                                                                                   \
-            if (lists_ && s->csg_small)                                                                                \
+            if (lists_ && s->isect_ll_bytes) {                                                                         \
+                if (!s->ll_attr_set) {                                                                                 \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_>),  \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);     \
+                    s->ll_attr_set = true;                                                                             \
+                }                                                                                                      \
                 LAUNCH_IS(C, M, T, L, true, lists_);                                                                   \
-            else                                                                                                       \
+            } else                                                                                                       \
                 LAUNCH_IS(C, M, T, L, true, false);                                                                    \
         } else {                                                                                                       \
-            if (lists_ && s->csg_small)                                                                                \
-                LAUNCH_IS(C, M, T, L, false, lists_);                                                                  \
-            else                                                                                                       \
-                LAUNCH_IS(C, M, T, L, false, false);                                                                   \
+            LAUNCH_IS(C, M, T, L, false, false);                                                                       \
         }                                                                                                              \
     } while (0)
     // scenes whose tables do not fit LDS (scene_lds_bytes == 0) run the one variant that reads them from memory,
@@ -625,17 +638,9 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
         if (blocks < resident) blocks = std::min<uint64_t>(resident, ((uint64_t)live + (RT_TAILG_LANES / 64) * RT_TAILG_MIN_LANES - 1) / ((RT_TAILG_LANES / 64) * RT_TAILG_MIN_LANES));
         if (blocks > 65535u * 16u) blocks = 65535u * 16u;
         if (blocks < 1) blocks = 1;
-#define LAUNCH_TGS(C, M, T, S)                                                                                         \
-    hipLaunchKernelGGL((k_tail_grid<C, M, T, S>), dim3((uint32_t)blocks), dim3(RT_TAILG_LANES), s->tail_grid_lds_bytes, st, s->dev, q, \
-                       w.d_counts, d_rgb, pp, w.d_guards, lane_totals)
 #define LAUNCH_TG(C, M, T)                                                                                             \
-    do {                                                                                                               \
-        constexpr bool lists_ = (C || M) && RT_CSG_SMALL_KERNELS;                                                      \
-        if (lists_ && s->csg_small)                                                                                    \
-            LAUNCH_TGS(C, M, T, lists_);                                                                               \
-        else                                                                                                           \
-            LAUNCH_TGS(C, M, T, false);                                                                                \
-    } while (0)
+    hipLaunchKernelGGL((k_tail_grid<C, M, T>), dim3((uint32_t)blocks), dim3(RT_TAILG_LANES), s->tail_grid_lds_bytes, st, s->dev, q, \
+                       w.d_counts, d_rgb, pp, w.d_guards, lane_totals)
         switch (variant) {
         case 0: LAUNCH_TG(false, false, false); break;
         case 1: LAUNCH_TG(false, false, true); break;
@@ -647,23 +652,14 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
         default: LAUNCH_TG(true, true, true); break;
         }
 #undef LAUNCH_TG
-#undef LAUNCH_TGS
         return;
     }
     uint64_t blocks = ((uint64_t)live * (s->has_mesh ? 64 : 1) + RT_BLOCK - 1) / RT_BLOCK; // wave or lane per path
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-#define LAUNCH_TS(C, M, T, L, S)                                                                                       \
-    hipLaunchKernelGGL((k_tail<C, M, T, L, S>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, w.d_counts,    \
-                       w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
 #define LAUNCH_T(C, M, T, L)                                                                                           \
-    do {                                                                                                               \
-        constexpr bool lists_ = (C || M) && L && RT_CSG_SMALL_KERNELS;                                                 \
-        if (lists_ && s->csg_small)                                                                                    \
-            LAUNCH_TS(C, M, T, L, lists_);                                                                             \
-        else                                                                                                           \
-            LAUNCH_TS(C, M, T, L, false);                                                                              \
-    } while (0)
+    hipLaunchKernelGGL((k_tail<C, M, T, L>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, w.d_counts,    \
+                       w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
     switch (variant) {
     case 0: LAUNCH_T(false, false, false, true); break;
     case 1: LAUNCH_T(false, false, true, true); break;
@@ -676,7 +672,6 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
     default: LAUNCH_T(true, true, true, false); break; // tables in memory: the general variant
     }
 #undef LAUNCH_T
-#undef LAUNCH_TS
 }
 
 typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
