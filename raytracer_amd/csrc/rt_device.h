@@ -82,8 +82,9 @@ struct DevObject {
     int32_t mesh0, n_meshes;
     int32_t material;
     int32_t needs_uv; // material's texture reads uv
-    int32_t has_bounds; // wmin/wmax hold world bounds of all leaves (DO_CSG, DO_MEDIUM, a torus leaf): a ray that
-                        // misses them meets no leaf, so the object is skipped without running its program
+    int32_t has_bounds; // bit 0: wmin/wmax hold world bounds of the primitives a ray must meet for the object to yield
+                        // anything (DO_CSG, DO_MEDIUM, a torus leaf): a ray that misses them skips the object without
+                        // running its program; bit 1: no hit of the object lies before those bounds either
     double density;
     double wmin[3], wmax[3];
 };

@@ -468,6 +468,73 @@ struct Flattener {
         return li;
     }
 
+    // World bounds of what a ray must meet for a subtree to yield any interval at all.  A primitive: its own bounds.
+    // A union: both operands' (either may yield).  A difference a - b: a's (csg.rs:216-218: nothing without a; what b
+    // does to the result - including the to_world the reference skips when b is missed - never adds a ray that a's
+    // primitives did not meet).  An intersection: one operand's, the smaller (both must be met; the boxes' common
+    // part would not do: a ray may meet the two boxes in different places).  `bounded` false: a plane somewhere
+    // the result depends on.
+    struct NeedBox {
+        bool bounded = true, any = false;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        void add(const NeedBox &o)
+        {
+            bounded = bounded && o.bounded;
+            any = any || o.any;
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::fmin(lo[k], o.lo[k]);
+                hi[k] = std::fmax(hi[k], o.hi[k]);
+            }
+        }
+        double area() const
+        {
+            if (!bounded || !any) return 1e300;
+            const double e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+            return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+        }
+    };
+
+    static NeedBox leaf_world_box(const DevLeaf &L)
+    {
+        NeedBox bx;
+        const double *p = L.p;
+        double b[6]; // leaf-space min xyz, max xyz
+        switch (L.kind) {
+        case DL_NONE: return bx; // a frame, no surface
+        case DL_SPHERE: {
+            const double r = std::sqrt(p[3]);
+            for (int k = 0; k < 3; ++k) {
+                b[k] = p[k] - r;
+                b[3 + k] = p[k] + r;
+            }
+            break;
+        }
+        case DL_RECT_XY: b[0] = p[4], b[3] = p[5], b[1] = p[6], b[4] = p[7], b[2] = b[5] = p[2]; break;
+        case DL_RECT_XZ: b[0] = p[4], b[3] = p[5], b[2] = p[6], b[5] = p[7], b[1] = b[4] = p[1]; break;
+        case DL_RECT_ZY: b[2] = p[4], b[5] = p[5], b[1] = p[6], b[4] = p[7], b[0] = b[3] = p[0]; break;
+        case DL_CUBE: b[0] = p[0], b[3] = p[5], b[1] = p[10], b[4] = p[15], b[2] = p[20], b[5] = p[25]; break;
+        case DL_CYLINDER: // whichever way the axis is placed along y
+            b[0] = b[2] = -p[0], b[3] = b[5] = p[0], b[1] = -std::fabs(p[1]), b[4] = std::fabs(p[1]);
+            break;
+        case DL_TORUS: {
+            const double r = std::fabs(p[0]) + std::fabs(p[1]);
+            for (int k = 0; k < 3; ++k) b[k] = -r, b[3 + k] = r;
+            break;
+        }
+        default: bx.bounded = false; return bx; // a plane: no bounds
+        }
+        bx.any = true;
+        for (int c = 0; c < 8; ++c) {
+            const double q[3] = {b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]};
+            for (int k = 0; k < 3; ++k) {
+                const double w = L.identity ? q[k] : q[0] * L.O.m[0 * 3 + k] + q[1] * L.O.m[1 * 3 + k] + q[2] * L.O.m[2 * 3 + k] + L.O.m[9 + k];
+                bx.lo[k] = std::fmin(bx.lo[k], w);
+                bx.hi[k] = std::fmax(bx.hi[k], w);
+            }
+        }
+        return bx;
+    }
+
     void check_stack(int idx)
     {
         const int need = stack_need(idx);
@@ -512,16 +579,16 @@ struct Flattener {
         return std::max(na, nb + 1);
     }
 
-    // anything that yields intervals: appends to the program (postfix)
-    void emit_intervals(int idx, const Mat4 &Wp, const Mat4 &Op, int leaf0)
+    // anything that yields intervals: appends to the program (postfix); returns the bounds a ray must meet (NeedBox)
+    NeedBox emit_intervals(int idx, const Mat4 &Wp, const Mat4 &Op, int leaf0)
     {
         const rt_shape_node &nd = node(idx);
         if (nd.kind == RT_SHAPE_MEDIUM) {
             // HomogenousMedium::intersection_intervals forwards the ray untouched
             // (homogenous_medium.rs:64-66): its own transformation plays no part here.
-            emit_intervals(nd.child_a, Wp, Op, leaf0);
-            return;
+            return emit_intervals(nd.child_a, Wp, Op, leaf0);
         }
+        NeedBox bx;
         Mat4 W, O;
         frames(nd, Wp, Op, W, O);
         switch (nd.kind) {
@@ -535,8 +602,16 @@ struct Flattener {
             // same (DEV_PROG_SKIP): W = world -> this node, p[0..8] = linear part of world -> parent,
             // O = (world -> parent) * (this node -> world), the map the normal misses.
             int skip_leaf = -1;
-            emit_intervals(nd.child_a, W, O, leaf0);
-            emit_intervals(nd.child_b, W, O, leaf0);
+            const NeedBox ba = emit_intervals(nd.child_a, W, O, leaf0);
+            const NeedBox bb = emit_intervals(nd.child_b, W, O, leaf0);
+            if (nd.kind == RT_SHAPE_UNION) {
+                bx = ba;
+                bx.add(bb);
+            } else if (nd.kind == RT_SHAPE_DIFFERENCE) {
+                bx = ba;
+            } else {
+                bx = ba.area() <= bb.area() ? ba : bb;
+            }
             if (nd.kind != RT_SHAPE_INTERSECTION && !linear_part_is_identity(mat_load(nd.o2w))) {
                 if (skip_count >= DEV_MAX_SKIPS)
                     throw Err{RT_ERR_UNSUPPORTED, "more than 20 unions/differences with a rotation or scale of their own in one object"};
@@ -561,9 +636,11 @@ struct Flattener {
             int rel = li - leaf0;
             if (rel >= DEV_MAX_LEAVES_PER_OBJECT) throw Err{RT_ERR_UNSUPPORTED, "too many primitives in one object"};
             out.prog.push_back((DEV_OP_LEAF << 24) | rel);
+            bx = leaf_world_box(out.leaves[li]);
             break;
         }
         }
+        return bx;
     }
 
     void emit_mesh(const rt_shape_node &nd, DevObject &obj)
@@ -907,6 +984,7 @@ struct Flattener {
 
         const rt_shape_node &root = node(ro.shape);
         Mat4 I = mat_identity();
+        NeedBox need; // what a ray must meet for the object to yield an interval (CSG programs, fog boundaries, primitives)
         switch (root.kind) {
         case RT_SHAPE_COMPOSITE: {
             obj.kind = DO_MESH;
@@ -936,12 +1014,12 @@ struct Flattener {
             obj.frame = push_leaf(DL_NONE, W, O);
             obj.leaf0 = (int)out.leaves.size();
             check_stack(root.child_a);
-            emit_intervals(root.child_a, W, O, obj.leaf0);
+            need = emit_intervals(root.child_a, W, O, obj.leaf0);
             break;
         }
         default: {
             check_stack(ro.shape);
-            emit_intervals(ro.shape, I, I, obj.leaf0);
+            need = emit_intervals(ro.shape, I, I, obj.leaf0);
             bool single = (out.prog.size() - (size_t)obj.prog0) == 1;
             obj.kind = single ? DO_LEAF : DO_CSG;
             bool entry_mode = root.kind == RT_SHAPE_CUBE || root.kind == RT_SHAPE_PLANE || root.kind == RT_SHAPE_XYRECT ||
@@ -954,57 +1032,20 @@ struct Flattener {
         obj.prog_len = (int)out.prog.size() - obj.prog0;
         if (obj.kind == DO_MEDIUM && obj.prog_len == 1) obj.prog_len = 0; // single boundary leaf
         if (obj.kind == DO_LEAF) obj.prog_len = 0;
-        // world bounds of all leaves, for the objects whose evaluation is expensive
+        // world bounds for the objects whose evaluation is expensive: of the primitives a ray must meet for the
+        // object to yield anything (NeedBox, above)
         bool wants_bounds = obj.kind == DO_CSG || obj.kind == DO_MEDIUM;
         for (int li = obj.leaf0; li < obj.leaf0 + obj.n_leaves; ++li)
             wants_bounds = wants_bounds || out.leaves[li].kind == DL_TORUS;
-        if (wants_bounds && obj.kind != DO_MESH) {
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            bool bounded = obj.n_leaves > 0;
-            for (int li = obj.leaf0; li < obj.leaf0 + obj.n_leaves && bounded; ++li) {
-                const DevLeaf &L = out.leaves[li];
-                const double *p = L.p;
-                double b[6]; // leaf-space min xyz, max xyz
-                switch (L.kind) {
-                case DL_NONE: continue; // a frame, no surface
-                case DL_SPHERE: {
-                    const double r = std::sqrt(p[3]);
-                    for (int k = 0; k < 3; ++k) {
-                        b[k] = p[k] - r;
-                        b[3 + k] = p[k] + r;
-                    }
-                    break;
-                }
-                case DL_RECT_XY: b[0] = p[4], b[3] = p[5], b[1] = p[6], b[4] = p[7], b[2] = b[5] = p[2]; break;
-                case DL_RECT_XZ: b[0] = p[4], b[3] = p[5], b[2] = p[6], b[5] = p[7], b[1] = b[4] = p[1]; break;
-                case DL_RECT_ZY: b[2] = p[4], b[5] = p[5], b[1] = p[6], b[4] = p[7], b[0] = b[3] = p[0]; break;
-                case DL_CUBE: b[0] = p[0], b[3] = p[5], b[1] = p[10], b[4] = p[15], b[2] = p[20], b[5] = p[25]; break;
-                case DL_CYLINDER: // whichever way the axis is placed along y
-                    b[0] = b[2] = -p[0], b[3] = b[5] = p[0], b[1] = -std::fabs(p[1]), b[4] = std::fabs(p[1]);
-                    break;
-                case DL_TORUS: {
-                    const double r = std::fabs(p[0]) + std::fabs(p[1]);
-                    for (int k = 0; k < 3; ++k) b[k] = -r, b[3 + k] = r;
-                    break;
-                }
-                default: bounded = false; continue; // a plane: no bounds
-                }
-                for (int c = 0; c < 8; ++c) {
-                    const double q[3] = {b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]};
-                    for (int k = 0; k < 3; ++k) {
-                        const double w = L.identity ? q[k] : q[0] * L.O.m[0 * 3 + k] + q[1] * L.O.m[1 * 3 + k] + q[2] * L.O.m[2 * 3 + k] + L.O.m[9 + k];
-                        lo[k] = std::fmin(lo[k], w);
-                        hi[k] = std::fmax(hi[k], w);
-                    }
-                }
-            }
-            if (bounded && lo[0] <= hi[0]) {
-                obj.has_bounds = 1;
-                for (int k = 0; k < 3; ++k) {
-                    const double padk = 1e-7 * (std::fmax(std::fabs(lo[k]), std::fabs(hi[k])) + 1.0);
-                    obj.wmin[k] = lo[k] - padk;
-                    obj.wmax[k] = hi[k] + padk;
-                }
+        if (wants_bounds && obj.kind != DO_MESH && need.bounded && need.any && need.lo[0] <= need.hi[0]) {
+            // bit 1: no hit of this object lies before its bounds.  Not so with a union or difference whose skipped
+            // to_world (DEV_PROG_SKIP) leaves a hit's t in the node's space: the hit may then appear nearer than
+            // the primitive it came from
+            obj.has_bounds = skip_count == 0 ? 3 : 1;
+            for (int k = 0; k < 3; ++k) {
+                const double padk = 1e-7 * (std::fmax(std::fabs(need.lo[k]), std::fabs(need.hi[k])) + 1.0);
+                obj.wmin[k] = need.lo[k] - padk;
+                obj.wmax[k] = need.hi[k] + padk;
             }
         }
         out.objects.push_back(obj);

@@ -215,6 +215,10 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
             t0 = fmax(t0, fmin(az, bz));
             t1 = fmin(t1, fmax(az, bz));
             if (t0 > t1 + 1e-9 * (fabs(t1) + 1.0)) continue;
+            // ... and one whose bounds begin behind the nearest hit so far cannot replace it (a later object must be
+            // strictly nearer, system.rs:125-129; the bounds are padded far beyond the rounding of either side) - bit 1
+            // of has_bounds: unless a skipped to_world may bring its hits nearer than its primitives (rt_flatten.cpp)
+            if ((ob.has_bounds & 2) && best_obj >= 0 && t0 > best_t) continue;
         }
         switch (ob.kind) {
         case DO_LEAF: c = eval_leaf_object<TORUS>(sc, ob, o, d, gd); break;
