@@ -138,13 +138,24 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
 // the meshes by brute force across the 64 lanes, the material - with no launch per bounce.
 // The late passes hold a fraction of a percent of the rays but were a sixth of the frame time
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
-template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS>
+// LL: the interval lists in LDS behind the scene tables, as in k_intersect (the same layout: RT_BLOCK == RT_ISECT_BLOCK)
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool LL>
 __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
                                                     uint32_t *lane_totals)
 {
+    static_assert(RT_BLOCK == RT_ISECT_BLOCK, "one layout of the LDS interval lists for both kernels");
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
+    LdsLists<RT_BLOCK> ll;
+    if (LL) {
+        unsigned char *lists_lds = reinterpret_cast<unsigned char *>(scene_lds) + ((scene_lds_bytes(sc_mem) + 15u) & ~15u);
+        ll.cap_ = (int)sc_mem.lds_list_cap;
+        ll.n_lists = (int)sc_mem.lds_list_n;
+        ll.t = reinterpret_cast<double *>(lists_lds) + threadIdx.x;
+        ll.tag = reinterpret_cast<uint32_t *>(lists_lds + (size_t)ll.n_lists * 2 * ll.cap_ * RT_BLOCK * 8) + threadIdx.x;
+        ll.counts = 0u;
+    }
     const uint32_t count = counts[pp.depth];
     // a scene with meshes: one wave per path (the 64 lanes share the mesh test); without: one lane per path
     const bool per_lane = !has_mesh;
@@ -164,7 +175,12 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
         PassParams p = pp;
         for (;;) {
             HitRec h;
-            bool wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, p, h, gd);
+            bool wants_mesh;
+            if constexpr (LL) {
+                wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS, true>(sc, o, d, pixel, p, h, gd, ll);
+            } else {
+                wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, p, h, gd);
+            }
             if (has_mesh && wants_mesh) {
                 int best_obj = h.obj;
                 double best_t = best_obj >= 0 ? h.t : DBL_MAX;

@@ -135,6 +135,7 @@ struct rt_scene {
     void *ws = nullptr;
     Workspace own;
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
+    bool ll_tail_attr_set = false;
     bool ll_attr_set = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this scene's LL variant on its device
     uint32_t isect_ll_bytes = 0; // dynamic LDS of k_intersect<.., LL = true> (scene tables + every lane's interval lists); 0: the lists stay in scratch memory
     uint64_t n_mesh_tris = 0;
@@ -657,9 +658,23 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
     uint64_t blocks = ((uint64_t)live * (s->has_mesh ? 64 : 1) + RT_BLOCK - 1) / RT_BLOCK; // wave or lane per path
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
+#define LAUNCH_TS(C, M, T, L, LL)                                                                                      \
+    hipLaunchKernelGGL((k_tail<C, M, T, L, LL>), dim3((uint32_t)blocks), dim3(RT_BLOCK), LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), \
+                       st, s->dev, q, w.d_counts, w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
+// (the variants with interval lists a second time with the lists in LDS, as k_intersect's)
 #define LAUNCH_T(C, M, T, L)                                                                                           \
-    hipLaunchKernelGGL((k_tail<C, M, T, L>), dim3((uint32_t)blocks), dim3(RT_BLOCK), scene_lds_bytes(s->dev), st, s->dev, q, w.d_counts,    \
-                       w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
+    do {                                                                                                               \
+        constexpr bool lists_ = (C || M) && L;                                                                         \
+        if (lists_ && s->isect_ll_bytes) {                                                                             \
+            if (!s->ll_tail_attr_set) {                                                                                \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail<C, M, T, L, lists_>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);         \
+                s->ll_tail_attr_set = true;                                                                            \
+            }                                                                                                          \
+            LAUNCH_TS(C, M, T, L, lists_);                                                                             \
+        } else                                                                                                         \
+            LAUNCH_TS(C, M, T, L, false);                                                                              \
+    } while (0)
     switch (variant) {
     case 0: LAUNCH_T(false, false, false, true); break;
     case 1: LAUNCH_T(false, false, true, true); break;
@@ -672,6 +687,7 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
     default: LAUNCH_T(true, true, true, false); break; // tables in memory: the general variant
     }
 #undef LAUNCH_T
+#undef LAUNCH_TS
 }
 
 typedef int (*stratum_fn)(void *user, uint32_t done, uint32_t total);
