@@ -127,7 +127,15 @@ struct DevMesh {
     uint32_t kd_index0; // base of this mesh's leaf-ordered triangle records
     uint32_t use_kd;    // this mesh is walked through its kd-tree (k_mesh<KD = true>), not its grid
     float crowd;        // triangles in the cell of an average (cell, triangle) reference of its grid
+    // Up to DEV_MESH_PARTS boxes (padded like bmin / bmax) that together hold every triangle, chosen by the flattener
+    // to have the least total surface: a ray that enters the mesh's bounds but none of these meets no triangle, so
+    // k_intersect does not queue it for the walk (LinkedTorus.obj: two thin rings in a box that is mostly empty -
+    // 45 % of the camera rays that cross the bounds miss all four parts).  n_parts 0: no such boxes (the bounds are
+    // as good).
+    uint32_t n_parts, pad_parts;
+    double part[4][6]; // min xyz, max xyz
 };
+#define DEV_MESH_PARTS 4
 
 // One (mesh object, mesh) pair, in the order Ray::trace / Composite::intersect would visit them:
 // everything k_mesh needs to start the walk of one mesh and to finish a hit, in one record (the

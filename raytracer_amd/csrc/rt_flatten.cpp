@@ -711,6 +711,89 @@ struct Flattener {
             dm.bmin[k] -= 2.0 * pad;
             dm.bmax[k] += 2.0 * pad;
         }
+        // Part boxes (DevMesh::part): the triangles split into up to DEV_MESH_PARTS groups, each time the group with the
+        // largest box cut where the two halves' boxes have the least surface (a sweep over the triangles sorted by
+        // centroid along each axis) - the chance that a ray crossing the mesh's bounds meets a box goes with its
+        // surface.  Kept when they shrink the total surface to under 85 %.
+        dm.n_parts = 0;
+        if (m.n_triangles >= 16 && !std::getenv("RT_NO_MESH_PARTS")) {
+            auto area_of = [](const Box &b) {
+                const double e[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]};
+                return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+            };
+            auto box_of = [&](const std::vector<uint32_t> &g) {
+                Box b;
+                for (int k = 0; k < 3; ++k) b.lo[k] = std::numeric_limits<double>::infinity(), b.hi[k] = -std::numeric_limits<double>::infinity();
+                for (uint32_t t : g)
+                    for (int k = 0; k < 3; ++k) {
+                        b.lo[k] = std::fmin(b.lo[k], pb[t].lo[k]);
+                        b.hi[k] = std::fmax(b.hi[k], pb[t].hi[k]);
+                    }
+                return b;
+            };
+            std::vector<std::vector<uint32_t>> groups(1);
+            groups[0].resize(m.n_triangles);
+            for (uint32_t t = 0; t < m.n_triangles; ++t) groups[0][t] = t;
+            while (groups.size() < DEV_MESH_PARTS) {
+                size_t gi = 0;
+                double worst = -1.0;
+                for (size_t k = 0; k < groups.size(); ++k) {
+                    const double a = groups[k].size() >= 2 ? area_of(box_of(groups[k])) : -1.0;
+                    if (a > worst) worst = a, gi = k;
+                }
+                if (worst <= 0.0) break;
+                std::vector<uint32_t> g = groups[gi];
+                double best_cost = std::numeric_limits<double>::infinity();
+                std::vector<uint32_t> best_order;
+                size_t best_at = 0;
+                for (int axis = 0; axis < 3; ++axis) {
+                    std::vector<uint32_t> order = g;
+                    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                        return pb[a].lo[axis] + pb[a].hi[axis] < pb[b].lo[axis] + pb[b].hi[axis];
+                    });
+                    std::vector<double> right(order.size() + 1, 0.0);
+                    Box acc;
+                    for (int k = 0; k < 3; ++k) acc.lo[k] = std::numeric_limits<double>::infinity(), acc.hi[k] = -std::numeric_limits<double>::infinity();
+                    for (size_t i = order.size(); i-- > 0;) {
+                        for (int k = 0; k < 3; ++k) {
+                            acc.lo[k] = std::fmin(acc.lo[k], pb[order[i]].lo[k]);
+                            acc.hi[k] = std::fmax(acc.hi[k], pb[order[i]].hi[k]);
+                        }
+                        right[i] = area_of(acc);
+                    }
+                    for (int k = 0; k < 3; ++k) acc.lo[k] = std::numeric_limits<double>::infinity(), acc.hi[k] = -std::numeric_limits<double>::infinity();
+                    for (size_t i = 0; i + 1 < order.size(); ++i) {
+                        for (int k = 0; k < 3; ++k) {
+                            acc.lo[k] = std::fmin(acc.lo[k], pb[order[i]].lo[k]);
+                            acc.hi[k] = std::fmax(acc.hi[k], pb[order[i]].hi[k]);
+                        }
+                        const double cost = area_of(acc) + right[i + 1];
+                        if (cost < best_cost) {
+                            best_cost = cost;
+                            best_at = i + 1;
+                            best_order = order;
+                        }
+                    }
+                }
+                if (best_order.empty()) break;
+                groups[gi].assign(best_order.begin(), best_order.begin() + (long)best_at);
+                groups.emplace_back(best_order.begin() + (long)best_at, best_order.end());
+            }
+            double total = 0.0;
+            for (const auto &g : groups) total += area_of(box_of(g));
+            Box whole;
+            for (int k = 0; k < 3; ++k) whole.lo[k] = dm.bmin[k], whole.hi[k] = dm.bmax[k];
+            if (groups.size() > 1 && total < 0.85 * area_of(whole)) {
+                dm.n_parts = (uint32_t)groups.size();
+                for (size_t gk = 0; gk < groups.size(); ++gk) {
+                    const Box b = box_of(groups[gk]);
+                    for (int k = 0; k < 3; ++k) {
+                        dm.part[gk][k] = b.lo[k] - 2.0 * pad;
+                        dm.part[gk][3 + k] = b.hi[k] + 2.0 * pad;
+                    }
+                }
+            }
+        }
         // resolution: about `density` cells per triangle, cells as close to cubes as the bounds
         // allow, and all grids of the scene together within the LDS budget of k_mesh
         double density = 2.0; // measured on MI355X with LinkedTorus.obj, k_mesh per 4K frame: 1.76 / 1.74 / 1.64 / 1.62 / 1.69 / 1.74 / 1.90 ms at 0.5 / 1 / 1.5 / 2 / 3 / 4 / 8 (with the f64 test alone 4 was best: longer lists cost more then)

@@ -114,7 +114,17 @@ RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3
     for (int mi = 0; mi < ob.n_meshes; ++mi) {
         const DevMesh &m = sc.meshes[ob.mesh0 + mi];
         double t0, t1;
-        any = any || (mesh_clip(m, ol, inv, t0, t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0));
+        bool met = mesh_clip(m, ol, inv, t0, t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0);
+        if (met && m.n_parts) {
+            // ... and one of the boxes that hold the triangles between them (DevMesh::part), likewise
+            met = false;
+            for (uint32_t k = 0; k < DEV_MESH_PARTS; ++k) {
+                if (k >= m.n_parts) break;
+                double p0, p1;
+                met = met || (box_clip(m.part[k], m.part[k] + 3, ol, inv, p0, p1) && p0 <= bound + 1e-9 * (fabs(p1) + 1.0));
+            }
+        }
+        any = any || met;
     }
     return any;
 }
