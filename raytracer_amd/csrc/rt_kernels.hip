@@ -458,7 +458,10 @@ static uint32_t grid_for_wide(uint64_t n)
 {
     uint64_t b = (n + RT_BLOCK_WIDE - 1) / RT_BLOCK_WIDE;
     if (b < 1) b = 1;
-    if (b > 256 * 2 * (1024 / RT_BLOCK_WIDE)) b = 256 * 2 * (1024 / RT_BLOCK_WIDE); // 2048 lanes per CU, grid-stride beyond
+    // what the chip holds at once of k_shade (162 registers: 3 waves per SIMD), grid-stride beyond: 4K mesh.scene, k_shade
+    // per frame alone 0.273 ms against 0.289 with 2048 workgroups (RT_SHADE_WGS: tuning knob, not API)
+    static const uint32_t shade_wgs = getenv("RT_SHADE_WGS") ? (uint32_t)atoi(getenv("RT_SHADE_WGS")) : 256u * 3u * (256u / RT_BLOCK_WIDE);
+    if (b > shade_wgs) b = shade_wgs;
     return (uint32_t)b;
 }
 
@@ -505,16 +508,24 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
 {
     uint64_t gb = ((uint64_t)live + RT_ISECT_BLOCK - 1) / RT_ISECT_BLOCK;
     if (gb < 1) gb = 1;
-    if (gb > 256 * 8) gb = 256 * 8; // 256 CUs x 8 blocks, grid-stride beyond that
+    // As many workgroups as the chip holds at once (256 CUs x the waves per SIMD the variant is compiled for: a
+    // workgroup is one wave on each of a CU's four SIMDs), grid-stride beyond that.  With 2048 workgroups of the plain
+    // variant (768 resident) the last third of the launch ran on two thirds of the chip: 4K mesh.scene, k_intersect per
+    // frame alone 0.970 ms at 2048 or 2304, 1.006 at 3072, 0.925 at 1536, 0.886 at 768.  RT_ISECT_WGS: tuning knob, not API.
+    static const uint32_t isect_wgs = getenv("RT_ISECT_WGS") ? (uint32_t)atoi(getenv("RT_ISECT_WGS")) : 0u;
     dim3 grid((uint32_t)gb), block(RT_ISECT_BLOCK);
+    static_assert(RT_ISECT_BLOCK == 256, "one wave per SIMD and workgroup");
     // the scene's one grid job goes to k_mesh_one, which leaves its triangle beside the record for k_shade to merge
     // (only long queues: short ones go to k_mesh_brute, which writes the hit record itself)
     const bool one = s->has_mesh && s->any_grid && s->mesh_pool_lds_bytes != 0u &&
                      (uint64_t)live * s->n_mesh_tris > (uint64_t)RT_BRUTE_MAX_TESTS;
 #define LAUNCH_IS(C, M, T, L, F, LL)                                                                                   \
-    hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
-                       count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work,    \
-                       one ? w.mres_tri : nullptr)
+    do {                                                                                                               \
+        grid.x = std::min<uint32_t>((uint32_t)gb, isect_wgs ? isect_wgs : 256u * (LL ? RT_LL_WAVES : (T ? RT_TORUS_WAVES : (M ? RT_MEDIUM_WAVES : (C ? RT_CSG_WAVES : RT_PLAIN_WAVES))))); \
+        hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
+                           count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, \
+                           one ? w.mres_tri : nullptr);                                                                \
+    } while (0)
 // the variants that hold interval lists (CSG programs, fog boundaries) exist a second time with the lists in LDS, for
 // the wavefront passes (fused) of scenes whose lists fit there
 #define LAUNCH_I(C, M, T, L)                                                                                           \
