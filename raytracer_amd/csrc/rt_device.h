@@ -134,6 +134,10 @@ struct DevMesh {
     // as good).
     uint32_t n_parts, pad_parts;
     double part[4][6]; // min xyz, max xyz
+    // the same boxes in world space (the bounds of their eight corners under the object's frame, padded again): what
+    // k_intersect tests, with the world ray as it is
+    double wbox[6];
+    double wpart[4][6];
 };
 #define DEV_MESH_PARTS 4
 

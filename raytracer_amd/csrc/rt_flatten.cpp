@@ -1111,6 +1111,33 @@ struct Flattener {
             break;
         }
         }
+        if (obj.kind == DO_MESH) {
+            // world-space copies of the meshes' bounds and part boxes, for k_intersect's conservative test
+            const DevLeaf &F = out.leaves[obj.frame];
+            auto to_world_box = [&](const double *lo, const double *hi, double *wb) {
+                double wl[3] = {1e300, 1e300, 1e300}, wh[3] = {-1e300, -1e300, -1e300};
+                for (int c = 0; c < 8; ++c) {
+                    const double q[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                    for (int k = 0; k < 3; ++k) {
+                        const double w = F.identity ? q[k] : q[0] * F.O.m[0 * 3 + k] + q[1] * F.O.m[1 * 3 + k] + q[2] * F.O.m[2 * 3 + k] + F.O.m[9 + k];
+                        wl[k] = std::fmin(wl[k], w);
+                        wh[k] = std::fmax(wh[k], w);
+                    }
+                }
+                double ext = 0.0;
+                for (int k = 0; k < 3; ++k) ext = std::fmax(ext, std::fmax(std::fabs(wl[k]), std::fabs(wh[k])));
+                const double padw = 4e-9 * (ext > 0.0 ? ext : 1.0);
+                for (int k = 0; k < 3; ++k) {
+                    wb[k] = wl[k] - padw;
+                    wb[3 + k] = wh[k] + padw;
+                }
+            };
+            for (int mi = obj.mesh0; mi < (int)out.meshes.size(); ++mi) {
+                DevMesh &dm = out.meshes[mi];
+                to_world_box(dm.bmin, dm.bmax, dm.wbox);
+                for (uint32_t k = 0; k < dm.n_parts; ++k) to_world_box(dm.part[k], dm.part[k] + 3, dm.wpart[k]);
+            }
+        }
         obj.n_leaves = (int)out.leaves.size() - obj.leaf0;
         obj.prog_len = (int)out.prog.size() - obj.prog0;
         if (obj.kind == DO_MEDIUM && obj.prog_len == 1) obj.prog_len = 0; // single boundary leaf

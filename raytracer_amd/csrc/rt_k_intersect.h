@@ -100,28 +100,24 @@ RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 
 // Does the ray need the walk through a mesh of this object?  Only a conservative answer is wanted here (k_mesh
 // applies the reference's own tests, mesh.rs:32-42,117, to every ray it is handed): the ray must enter the
 // padded bounds of the mesh's triangles at t >= 0 and before the nearest hit found among the other objects
-// (`have_hit`, `best_t`; slack keeps ties in play).  Those bounds lie inside the Mesh::new box, so a ray that
-// misses them meets no triangle.  The object-space direction is left un-normalised: the slab parameters are
-// then the world ray's own, no square root, no division beyond the three reciprocals.
-RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 d, bool have_hit, double best_t)
+// (`have_hit`, `best_t`; slack keeps ties in play) - and, where the flattener found them worth having, one of the
+// boxes that hold the triangles between them (DevMesh::part).  Those bounds lie inside the Mesh::new box, so a ray
+// that misses them meets no triangle.  The test is made in world space, on the boxes' world bounds (DevMesh::wbox,
+// wpart): the ray as it is, no transform, no square root, the slab parameters the world ray's own.
+RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 inv, bool have_hit, double best_t)
 {
-    const DevLeaf &F = sc.leaves[ob.frame];
-    const d3 ol = F.identity ? o : xf_point(F.W, o);
-    const d3 dl = F.identity ? d : xf_dir(F.W, d);
-    const d3 inv = mk3(1.0 / dl.x, 1.0 / dl.y, 1.0 / dl.z);
     const double bound = have_hit ? best_t * (1.0 + 1e-7) + 1e-7 : 1.0e300;
     bool any = false;
     for (int mi = 0; mi < ob.n_meshes; ++mi) {
         const DevMesh &m = sc.meshes[ob.mesh0 + mi];
         double t0, t1;
-        bool met = mesh_clip(m, ol, inv, t0, t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0);
+        bool met = box_clip(m.wbox, m.wbox + 3, o, inv, t0, t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0);
         if (met && m.n_parts) {
-            // ... and one of the boxes that hold the triangles between them (DevMesh::part), likewise
             met = false;
             for (uint32_t k = 0; k < DEV_MESH_PARTS; ++k) {
                 if (k >= m.n_parts) break;
                 double p0, p1;
-                met = met || (box_clip(m.part[k], m.part[k] + 3, ol, inv, p0, p1) && p0 <= bound + 1e-9 * (fabs(p1) + 1.0));
+                met = met || (box_clip(m.wpart[k], m.wpart[k] + 3, o, inv, p0, p1) && p0 <= bound + 1e-9 * (fabs(p1) + 1.0));
             }
         }
         any = any || met;
@@ -250,9 +246,10 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 
     if (wants_mesh) {
         wants_mesh = false;
+        const d3 inv_m = (CSG || MEDIUM || TORUS) ? inv_w : mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
         for (int k = 0; k < sc.n_objects; ++k) {
             const DevObject &ob = sc.objects[k];
-            if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, d, best_obj >= 0, best_t);
+            if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, inv_m, best_obj >= 0, best_t);
         }
     }
 

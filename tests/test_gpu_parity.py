@@ -931,6 +931,58 @@ def test_mesh_kernels_agree(rt, monkeypatch):
         assert np.array_equal(out[0][3][k], out[1][3][k]), k
 
 
+def test_interval_lists_in_lds_and_in_scratch_agree(rt, monkeypatch):
+    """The CSG / fog variants of k_intersect and k_tail keep a ray's interval lists in LDS when the scene's bounds on them
+    fit (rt_scene_create; LdsLists, rt_dev_shapes.h) and in scratch memory otherwise (RT_LDS_LISTS=0 forces that): the
+    same interval algebra on another store, so frames, ids and ray counts are equal bit for bit - on the shipped CSG and
+    fog scenes, on fuzz scenes with transforms at every level of their trees, and on traced ray batches."""
+    cases = [(parity.scene_path(n), None) for n in ("csg", "room", "fog_light", "csg_notorus")]
+    cases += [(None, fuzz_scenes.scene_text(seed, torus=(seed % 2 == 0))) for seed in (61, 64, 70, 76, 78)]
+    for path, text in cases:
+        o = rt.Options(width=200, height=150, samples=4, seed=5)
+        sc = rt.parse_file(o, path, parity.ASSETS) if path else rt.parse(o, text, parity.ASSETS)
+        ro, rd = _random_rays(20000, 6, np.array([0.0, 1.0, 0.0]), 3.0)
+        out = []
+        for lds in ("1", "0"):
+            monkeypatch.setenv("RT_LDS_LISTS", lds)
+            dev = rt.DeviceScene(sc)
+            rgb, ids, st = dev.render(o)
+            got, _ = dev.trace_rays(ro, rd, seed=4)
+            out.append((rgb, ids, st.rays, list(st.guards), st.interval_overflow, got))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), path or text[:80]
+        assert out[0][2:5] == out[1][2:5] and out[0][4] == 0
+        for k in ("object", "t", "n", "uv"):
+            assert np.array_equal(out[0][5][k], out[1][5][k]), k
+
+
+def test_mesh_part_boxes_only_drop_rays_that_miss(rt, monkeypatch):
+    """DevMesh::part (rt_flatten.cpp): k_intersect queues a ray for the mesh walk only if it enters one of up to four boxes
+    that hold every triangle between them.  A ray it drops has no triangle to meet, so the frame with the boxes equals
+    the frame without (RT_NO_MESH_PARTS=1) bit for bit - also under a rotated and scaled mesh object - while fewer rays
+    go through the mesh queue."""
+    texts = [open(parity.scene_path("mesh")).read(),
+             'camera { origin <1.5, 2.5, 5> look_at <0, 0.8, 0> }\n'
+             'object "light" { sphere { origin <4, 6, 3> radius 2 } material { diffuse_light intensity 4 texture { solid color white } } }\n'
+             'object "floor" { plane { origin <0, -0.6, 0> normal <0, 1, 0> } material { lambertian texture { pattern { checkerboard color rgb <1, 1, 1> color rgb <0.2, 0.2, 0.6> 1 } } } }\n'
+             'object "a" { mesh { file "LinkedTorus.obj" transform { scale <1.3, 0.7, 1.1> rotate_x 35 rotate_y 20 translate <0.2, 0.9, -0.3> } } material { metal fuzz 0.1 texture { solid color rgb <0.8, 0.8, 0.3> } } }\n',
+             open(parity.scene_path("mesh")).read().replace("LinkedTorus.obj", "Monkey.obj")]
+    for text in texts:
+        o = rt.Options(width=320, height=200, samples=4, seed=11, stage_times=True)
+        sc = rt.parse(o, text, parity.ASSETS)
+        out = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("RT_NO_MESH_PARTS", "1")
+            else:
+                monkeypatch.delenv("RT_NO_MESH_PARTS", raising=False)
+            dev = rt.DeviceScene(sc)
+            rgb, ids, st = dev.render(o)
+            out.append((rgb, ids, st.rays, st.mesh_records))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+        assert out[0][3] <= out[1][3]
+    assert out[0][3] > 0
+
+
 def test_stats_name_the_mesh_kernel(rt, monkeypatch):
     """rt_stats.mesh_one_rays: all of mesh_rays in a scene with one mesh job (k_mesh_one walked the grid), none when the
     scene has two jobs (two mesh objects: k_mesh) or when RT_MESH_POOL=0 keeps k_mesh; mesh_records counts every ray that
