@@ -78,7 +78,12 @@ struct HitBuf {
 #ifndef RT_LL_WAVES
 #define RT_LL_WAVES 2
 #endif
-#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(LL ? RT_LL_WAVES : (TORUS ? RT_TORUS_WAVES : (MEDIUM ? RT_MEDIUM_WAVES : (CSG ? RT_CSG_WAVES : RT_PLAIN_WAVES))))))
+// the plain variant on a ray queue (PQ == 2): RT_QUEUE_WAVES
+#ifndef RT_QUEUE_WAVES
+#define RT_QUEUE_WAVES RT_PLAIN_WAVES
+#endif
+#define RT_ISECT_WAVES(C, M, T, LL, PQ) ((LL) ? RT_LL_WAVES : ((T) ? RT_TORUS_WAVES : ((M) ? RT_MEDIUM_WAVES : ((C) ? RT_CSG_WAVES : ((PQ) == 2 ? RT_QUEUE_WAVES : RT_PLAIN_WAVES)))))
+#define RT_ISECT_OCC __attribute__((amdgpu_waves_per_eu(RT_ISECT_WAVES(CSG, MEDIUM, TORUS, LL, PQ))))
 
 struct PassParams {
     uint64_t seed;

@@ -325,7 +325,10 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 // in their slot field so that k_copy_mesh_hits can put the merged hit back.
 // LL: the interval lists of the CSG / fog variants in LDS behind the scene tables (sc_mem.lds_list_cap intervals per
 // list, sc_mem.lds_list_n lists per ray: the launch code has checked that two workgroups per CU find room)
-template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED, bool LL>
+// PQ: 0 - whether the queue is the primary one (camera rays regenerated from the slot number) is read from the queue at
+// run time; 1 / 2 - it is known to be the primary one / a ray queue, and the other half's code, pointers and registers
+// are not in the kernel (the wavefront loop launches these; 2 may also run at another occupancy, RT_QUEUE_WAVES)
+template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED, bool LL, int PQ>
 __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
                                                          RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
@@ -361,9 +364,21 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
         h.n = mk3(0, 0, 0);
         h.u = h.v = 0.0;
         h.obj = -1;
-        if (i < count && fetch_ray(sc, q, pp, i, o, d, pixel)) {
+        const bool primary = PQ == 0 ? q.primary != 0 : PQ == 1;
+        bool have;
+        if (primary) {
+            have = i < count && primary_ray(sc, q, pp, i, o, d, pixel);
+        } else {
+            have = i < count;
+            if (have) {
+                o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
+                d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
+                pixel = q.pixel[i];
+            }
+        }
+        if (have) {
             if (FUSED) {
-                if (q.primary) {
+                if (primary) {
                     slot = q.row_major ? pixel : i;
                 } else {
                     slot = q.slot[i];
@@ -375,7 +390,7 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
             } else {
                 wants_mesh = intersect_analytic<CSG, MEDIUM, TORUS>(sc, o, d, pixel, pp, h, gd);
             }
-            if (primary_ids) primary_ids[FUSED ? slot : ray_slot(q, i)] = h.obj;
+            if (primary_ids && (PQ != 2 || !FUSED)) primary_ids[FUSED ? slot : ray_slot(q, i)] = h.obj;
             if (!FUSED) {
                 hit.t[i] = h.t;
                 hit.n[0][i] = h.n.x;

@@ -519,12 +519,22 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     // (only long queues: short ones go to k_mesh_brute, which writes the hit record itself)
     const bool one = s->has_mesh && s->any_grid && s->mesh_pool_lds_bytes != 0u &&
                      (uint64_t)live * s->n_mesh_tris > (uint64_t)RT_BRUTE_MAX_TESTS;
-#define LAUNCH_IS(C, M, T, L, F, LL)                                                                                   \
+#define LAUNCH_ISP(C, M, T, L, F, LL, PQ)                                                                              \
     do {                                                                                                               \
-        grid.x = std::min<uint32_t>((uint32_t)gb, isect_wgs ? isect_wgs : 256u * (LL ? RT_LL_WAVES : (T ? RT_TORUS_WAVES : (M ? RT_MEDIUM_WAVES : (C ? RT_CSG_WAVES : RT_PLAIN_WAVES))))); \
-        hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
+        grid.x = std::min<uint32_t>((uint32_t)gb, isect_wgs ? isect_wgs : 256u * RT_ISECT_WAVES(C, M, T, LL, PQ));     \
+        hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL, PQ>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
                            count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, \
                            one ? w.mres_tri : nullptr);                                                                \
+    } while (0)
+// the wavefront passes (fused) know which kind of queue they read: the kernel without the other kind's code
+#define LAUNCH_IS(C, M, T, L, F, LL)                                                                                   \
+    do {                                                                                                               \
+        if (!F)                                                                                                        \
+            LAUNCH_ISP(C, M, T, L, F, LL, (F ? 1 : 0));                                                                \
+        else if (q.primary)                                                                                            \
+            LAUNCH_ISP(C, M, T, L, F, LL, (F ? 1 : 0));                                                                \
+        else                                                                                                           \
+            LAUNCH_ISP(C, M, T, L, F, LL, (F ? 2 : 0));                                                                \
     } while (0)
 // the variants that hold interval lists (CSG programs, fog boundaries) exist a second time with the lists in LDS, for
 // the wavefront passes (fused) of scenes whose lists fit there
@@ -534,12 +544,14 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
         if (fused) {                                                                                                   \
             if (lists_ && s->isect_ll_bytes) {                                                                         \
                 if (!s->ll_attr_set) {                                                                                 \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_>),  \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 1>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);     \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 2>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);     \
                     s->ll_attr_set = true;                                                                             \
                 }                                                                                                      \
                 LAUNCH_IS(C, M, T, L, true, lists_);                                                                   \
-            } else                                                                                                       \
+            } else                                                                                                     \
                 LAUNCH_IS(C, M, T, L, true, false);                                                                    \
         } else {                                                                                                       \
             LAUNCH_IS(C, M, T, L, false, false);                                                                       \
