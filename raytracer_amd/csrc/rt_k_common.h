@@ -73,7 +73,11 @@ struct HitBuf {
 #define RT_TAIL_WAVES 3 // 4K mesh.scene tail 0.36 -> 0.34 ms against 2 (41 spilled registers); cornell_box 0.26 -> 0.27
 #endif
 // k_tail without CSG / fog / torus code (the bench scene's variant): waves per SIMD it is compiled for
-#define RT_TAIL_OCC __attribute__((amdgpu_waves_per_eu((CSG || MEDIUM || TORUS) ? 1 : RT_TAIL_WAVES)))
+// ... with CSG / fog / torus code: RT_TAIL_HEAVY_WAVES
+#ifndef RT_TAIL_HEAVY_WAVES
+#define RT_TAIL_HEAVY_WAVES 2
+#endif
+#define RT_TAIL_OCC __attribute__((amdgpu_waves_per_eu((CSG || MEDIUM || TORUS) ? RT_TAIL_HEAVY_WAVES : RT_TAIL_WAVES)))
 // ... and the variants with their interval lists in LDS at RT_LL_WAVES: the lists of two workgroups fill a CU's LDS
 #ifndef RT_LL_WAVES
 #define RT_LL_WAVES 2

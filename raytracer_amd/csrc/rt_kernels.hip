@@ -820,8 +820,9 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                 if (!s->has_mesh) {
                     // one lane per path and nothing shared between lanes: the launch lasts as long as its deepest path
                     // whether it holds 16 k paths or as many as the chip holds at once (the variants with CSG, fog or
-                    // torus code are compiled for one wave per SIMD: 65 k lanes), while every pass it replaces has its floor
-                    const uint32_t resident = (s->has_csg || s->has_medium || s->has_torus) ? 65536u : tail_paths;
+                    // torus code are compiled for RT_TAIL_HEAVY_WAVES waves per SIMD: 65 k lanes each), while every pass it
+                    // replaces has its floor
+                    const uint32_t resident = (s->has_csg || s->has_medium || s->has_torus) ? 65536u * RT_TAIL_HEAVY_WAVES : tail_paths;
                     tail_max = std::max(tail_max, std::min(n_slots / 6u, std::min(resident, tail_paths)));
                 }
                 if (tail_env != 0xFFFFFFFFu) tail_max = tail_env;
