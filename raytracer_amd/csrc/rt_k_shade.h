@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
                                                     uint32_t *lane_totals)
 {
-    static_assert(RT_BLOCK == RT_ISECT_BLOCK, "one layout of the LDS interval lists for both kernels");
+    static_assert(!LL || RT_BLOCK == RT_ISECT_BLOCK, "one layout of the LDS interval lists for both kernels");
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
     LdsLists<RT_BLOCK> ll;

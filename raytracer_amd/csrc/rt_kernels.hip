@@ -398,7 +398,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
         const bool off = e && !strcmp(e, "0");
         // (the kernel's static LDS - the append's words - and the allocation granularity take a little more: 1 KB each)
         if (!off && scene_lds_bytes(s->dev) != 0u && cap <= DEV_LDS_LIST_MAX_INTERVALS && lists <= DEV_LDS_LIST_MAX_LISTS &&
-            want + 1024u <= (uint64_t)lds_limit / RT_LL_WAVES) {
+            want + 1024u <= (uint64_t)lds_limit * RT_ISECT_BLOCK / (RT_LL_WAVES * 256u)) { // RT_LL_WAVES x 256 / RT_ISECT_BLOCK workgroups per CU
             s->isect_ll_bytes = (uint32_t)want;
             s->dev.lds_list_cap = cap;
             s->dev.lds_list_n = lists;
@@ -514,14 +514,14 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     // frame alone 0.970 ms at 2048 or 2304, 1.006 at 3072, 0.925 at 1536, 0.886 at 768.  RT_ISECT_WGS: tuning knob, not API.
     static const uint32_t isect_wgs = getenv("RT_ISECT_WGS") ? (uint32_t)atoi(getenv("RT_ISECT_WGS")) : 0u;
     dim3 grid((uint32_t)gb), block(RT_ISECT_BLOCK);
-    static_assert(RT_ISECT_BLOCK == 256, "one wave per SIMD and workgroup");
+    static_assert(RT_ISECT_BLOCK == 128 || RT_ISECT_BLOCK == 256 || RT_ISECT_BLOCK == 512, "workgroups of k_intersect");
     // the scene's one grid job goes to k_mesh_one, which leaves its triangle beside the record for k_shade to merge
     // (only long queues: short ones go to k_mesh_brute, which writes the hit record itself)
     const bool one = s->has_mesh && s->any_grid && s->mesh_pool_lds_bytes != 0u &&
                      (uint64_t)live * s->n_mesh_tris > (uint64_t)RT_BRUTE_MAX_TESTS;
 #define LAUNCH_ISP(C, M, T, L, F, LL, PQ)                                                                              \
     do {                                                                                                               \
-        grid.x = std::min<uint32_t>((uint32_t)gb, isect_wgs ? isect_wgs : 256u * RT_ISECT_WAVES(C, M, T, LL, PQ));     \
+        grid.x = std::min<uint32_t>((uint32_t)gb, isect_wgs ? isect_wgs : 256u * RT_ISECT_WAVES(C, M, T, LL, PQ) * 256u / RT_ISECT_BLOCK); \
         hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL, PQ>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
                            count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, \
                            one ? w.mres_tri : nullptr);                                                                \
@@ -687,7 +687,7 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
 // (the variants with interval lists a second time with the lists in LDS, as k_intersect's)
 #define LAUNCH_T(C, M, T, L)                                                                                           \
     do {                                                                                                               \
-        constexpr bool lists_ = (C || M) && L;                                                                         \
+        constexpr bool lists_ = (C || M) && L && RT_BLOCK == RT_ISECT_BLOCK; /* one layout of the lists for both kernels */ \
         if (lists_ && s->isect_ll_bytes) {                                                                             \
             if (!s->ll_tail_attr_set) {                                                                                \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail<C, M, T, L, lists_>),                 \
