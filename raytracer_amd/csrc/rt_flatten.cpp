@@ -1126,7 +1126,7 @@ struct Flattener {
                 }
                 double ext = 0.0;
                 for (int k = 0; k < 3; ++k) ext = std::fmax(ext, std::fmax(std::fabs(wl[k]), std::fabs(wh[k])));
-                const double padw = 4e-9 * (ext > 0.0 ? ext : 1.0);
+                const double padw = 1e-7 * (ext > 0.0 ? ext : 1.0); // (k_intersect's test uses approximate reciprocals)
                 for (int k = 0; k < 3; ++k) {
                     wb[k] = wl[k] - padw;
                     wb[3 + k] = wh[k] + padw;

@@ -104,20 +104,43 @@ RT_CSG_FN Candidate eval_csg_object(const DevScene &sc, const DevObject &ob, d3 
 // boxes that hold the triangles between them (DevMesh::part).  Those bounds lie inside the Mesh::new box, so a ray
 // that misses them meets no triangle.  The test is made in world space, on the boxes' world bounds (DevMesh::wbox,
 // wpart): the ray as it is, no transform, no square root, the slab parameters the world ray's own.
-RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 inv, bool have_hit, double best_t)
+// (This test took 18 % of k_intersect's wave time with exact divisions and box_clip's branches,
+// profiles/r03e_isect_wave_time.txt: being conservative it needs neither - the reciprocals are the hardware's
+// approximation refined once, 2^-40 or better, the slabs are min / max chains in which a NaN (0 x inf: the ray runs
+// inside a face's plane) drops out, and the world boxes are padded by 1e-7 of their size, rt_flatten.cpp.)
+RT_DEV double approx_recip(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    const double r1 = fma(r, fma(-x, r, 1.0), r);
+    return (r1 == r1 && fabs(r1) <= 1.0e300) ? r1 : r; // x = 0, denormal or huge: the hardware's own answer (inf, 0)
+}
+RT_DEV bool slab_enters(const double *b, d3 o, d3 inv, double bound)
+{
+    double t0 = 0.0, t1 = 1.0e300;
+    const double ax = (b[0] - o.x) * inv.x, bx = (b[3] - o.x) * inv.x;
+    t0 = fmax(t0, fmin(ax, bx));
+    t1 = fmin(t1, fmax(ax, bx));
+    const double ay = (b[1] - o.y) * inv.y, by = (b[4] - o.y) * inv.y;
+    t0 = fmax(t0, fmin(ay, by));
+    t1 = fmin(t1, fmax(ay, by));
+    const double az = (b[2] - o.z) * inv.z, bz = (b[5] - o.z) * inv.z;
+    t0 = fmax(t0, fmin(az, bz));
+    t1 = fmin(t1, fmax(az, bz));
+    return !(t0 > t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0);
+}
+RT_DEV bool mesh_object_wanted(const DevScene &sc, const DevObject &ob, d3 o, d3 d, bool have_hit, double best_t)
 {
     const double bound = have_hit ? best_t * (1.0 + 1e-7) + 1e-7 : 1.0e300;
+    const d3 inv = mk3(approx_recip(d.x), approx_recip(d.y), approx_recip(d.z));
     bool any = false;
     for (int mi = 0; mi < ob.n_meshes; ++mi) {
         const DevMesh &m = sc.meshes[ob.mesh0 + mi];
-        double t0, t1;
-        bool met = box_clip(m.wbox, m.wbox + 3, o, inv, t0, t1) && t0 <= bound + 1e-9 * (fabs(t1) + 1.0);
+        bool met = slab_enters(m.wbox, o, inv, bound);
         if (met && m.n_parts) {
             met = false;
             for (uint32_t k = 0; k < DEV_MESH_PARTS; ++k) {
                 if (k >= m.n_parts) break;
-                double p0, p1;
-                met = met || (box_clip(m.wpart[k], m.wpart[k] + 3, o, inv, p0, p1) && p0 <= bound + 1e-9 * (fabs(p1) + 1.0));
+                met = met || slab_enters(m.wpart[k], o, inv, bound);
             }
         }
         any = any || met;
@@ -246,10 +269,9 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 
     if (wants_mesh) {
         wants_mesh = false;
-        const d3 inv_m = (CSG || MEDIUM || TORUS) ? inv_w : mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
         for (int k = 0; k < sc.n_objects; ++k) {
             const DevObject &ob = sc.objects[k];
-            if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, inv_m, best_obj >= 0, best_t);
+            if (ob.kind == DO_MESH) wants_mesh = wants_mesh || mesh_object_wanted(sc, ob, o, d, best_obj >= 0, best_t);
         }
     }
 
