@@ -133,4 +133,57 @@ int probe_pretest(const rt_scene_desc *desc, uint32_t rays_per_cell, uint64_t se
     }
     return 0;
 }
+
+// What the flattener decides about bounds (round 3): per object the world bounds of the primitives a ray must meet
+// (DevObject::has_bounds, wmin, wmax), per mesh the part boxes that hold its triangles between them, in object and in
+// world space, and the scene's bounds on its interval lists.
+//   iout: [0] objects, [1] meshes, [2] max_intervals, [3] max_stack, [8 + k] has_bounds of object k (k < 16),
+//         [32 + 2m] n_parts of mesh m (m < 4), [33 + 2m] triangles of mesh m with a vertex outside every part box
+//   dout: [6k ..] wmin, wmax of object k; [128 + 64m ..] bmin, bmax, part[4][6], wbox, wpart[4][6] of mesh m
+int probe_flat_bounds(const rt_scene_desc *desc, uint64_t *iout, double *dout)
+{
+    rt_host::FlatScene flat;
+    std::string err;
+    int rc = rt_host::flatten_scene(desc, flat, err);
+    if (rc) return rc;
+    iout[0] = flat.objects.size();
+    iout[1] = flat.meshes.size();
+    iout[2] = (uint64_t)flat.max_intervals;
+    iout[3] = (uint64_t)flat.max_stack;
+    for (size_t k = 0; k < flat.objects.size() && k < 16; ++k) {
+        iout[8 + k] = (uint64_t)flat.objects[k].has_bounds;
+        for (int c = 0; c < 3; ++c) {
+            dout[6 * k + c] = flat.objects[k].wmin[c];
+            dout[6 * k + 3 + c] = flat.objects[k].wmax[c];
+        }
+    }
+    for (size_t m = 0; m < flat.meshes.size() && m < 4; ++m) {
+        const DevMesh &M = flat.meshes[m];
+        iout[32 + 2 * m] = M.n_parts;
+        uint64_t outside = 0;
+        for (uint32_t t = 0; t < M.n_tris; ++t) {
+            const double *tr = flat.tris.data() + ((size_t)M.tri0 + t) * 9; // v0, v0v1, v0v2
+            bool covered = false;
+            for (uint32_t p = 0; p < M.n_parts && !covered; ++p) {
+                bool in = true;
+                for (int v = 0; v < 3 && in; ++v)
+                    for (int c = 0; c < 3 && in; ++c) {
+                        const double x = tr[c] + (v ? tr[3 * v + c] : 0.0);
+                        in = x >= M.part[p][c] && x <= M.part[p][3 + c];
+                    }
+                covered = in;
+            }
+            if (!covered) ++outside;
+        }
+        iout[33 + 2 * m] = outside;
+        double *d = dout + 128 + 64 * m;
+        for (int c = 0; c < 3; ++c) d[c] = M.bmin[c], d[3 + c] = M.bmax[c];
+        for (int p = 0; p < 4; ++p)
+            for (int c = 0; c < 6; ++c) d[6 + 6 * p + c] = M.part[p][c];
+        for (int c = 0; c < 6; ++c) d[30 + c] = M.wbox[c];
+        for (int p = 0; p < 4; ++p)
+            for (int c = 0; c < 6; ++c) d[36 + 6 * p + c] = M.wpart[p][c];
+    }
+    return 0;
+}
 }

@@ -495,3 +495,74 @@ def test_f32_pretest_never_rejects_a_hit(rt, tmp_path):
         assert jobs >= 1 and cells > 20 and tested > (100000 if cells > 200 else 5000) and hits > tested // 200, (mesh, list(out))
         assert missed == 0 and aimed >= 20, (mesh, list(out))
         assert passed < 2.0 * hits, (mesh, list(out))
+
+
+def test_flattener_bounds_and_part_boxes(rt):
+    """What rt_flatten.cpp decides about bounds (host code, probed through tests/helpers/pretest_probe.cpp):
+    * an expensive object carries the world bounds of the primitives a ray MUST meet - a difference its first
+      operand's, an intersection the smaller operand's, a union both (csg.scene's object: the cube, not the hull of
+      cube, spheres and torus); bit 1 of has_bounds (no hit lies before the bounds) only without a union / difference
+      that has a rotation or scale of its own;
+    * a mesh carries up to four part boxes that hold every triangle between them, with less surface than its bounds,
+      and world-space boxes that contain them under the object's frame;
+    * the scene's bounds on its interval lists (what decides whether they live in LDS)."""
+    lib = _pretest_probe()
+    lib.probe_flat_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.probe_flat_bounds.restype = C.c_int
+    o = rt.Options(width=8, height=8)
+
+    def probe(sc):
+        iout, dout = (C.c_uint64 * 64)(), (C.c_double * 512)()
+        assert lib.probe_flat_bounds(C.cast(sc.desc, C.c_void_p), iout, dout) == 0
+        return [int(v) for v in iout], np.array(dout[:])
+
+    def close(a, b, tol=1e-5):
+        return np.allclose(a, b, rtol=0, atol=tol)
+
+    # csg.scene: light, floor, thing = ((cube ^ sphere) - sphere) - torus
+    i, d = probe(rt.parse_file(o, parity.scene_path("csg"), parity.ASSETS))
+    assert i[0] == 3 and i[2] == 4 and i[3] == 2
+    assert i[8 + 2] == 3 and close(d[12:18], [-1, 0, -1, 1, 2, 1])
+    # room.scene: sky = sphere - sphere, earth, walls = (cube - cube) - cube, window, ball
+    i, d = probe(rt.parse_file(o, parity.scene_path("room"), parity.ASSETS))
+    assert i[2] == 3 and i[3] == 2
+    assert i[8] == 3 and close(d[0:6], [-1000.1, -1900.1, -1000.1, 1000.1, 100.1, 1000.1], 1e-3)
+    assert i[8 + 2] == 3 and close(d[12:18], [-5.1, -0.1, -5.1, 5.1, 8.1, 5.1])
+    assert i[8 + 1] == 0 and i[8 + 3] == 0 and i[8 + 4] == 0  # plane, cube, sphere: cheap objects carry none
+    i, d = probe(rt.parse_file(o, parity.scene_path("fog_light"), parity.ASSETS))
+    assert i[2] == 2 and i[3] == 2
+    text = ('camera { origin <0, 1, 6> look_at <0, 1, 0> }\n'
+            'object "a" { difference { sphere { origin <0, 1, 0> radius 1 } cube { <-2, 1, -2> <2, 3, 2> } transform { scale <2, 1, 1> } } material { lambertian texture { solid color white } } }\n'
+            'object "b" { union { sphere { origin <3, 1, 0> radius 1 } sphere { origin <5, 1, 0> radius 0.5 } } material { lambertian texture { solid color white } } }\n'
+            'object "c" { intersection { sphere { origin <0, 5, 0> radius 3 } cube { <-1, 4, -1> <1, 6, 1> } } material { lambertian texture { solid color white } } }\n'
+)
+    i, d = probe(rt.parse(o, text, parity.ASSETS))
+    assert i[8] == 1 and close(d[0:6], [-2, 0, -1, 2, 2, 1])        # scaled difference: its sphere, and hits may lie before it
+    assert i[8 + 1] == 3 and close(d[6:12], [2, 0, -1, 5.5, 2, 1])  # union: both
+    assert i[8 + 2] == 3 and close(d[12:18], [-1, 4, -1, 1, 6, 1])  # intersection: the cube (less surface than the sphere)
+    # (a plane inside a CSG tree - no bounds then - is not in the grammar: sdl_grammar.rs allows solids only)
+    # meshes
+    for mesh, xf in (("LinkedTorus.obj", "translate <0, 1, 0>"), ("Monkey.obj", "scale <1.3, 0.7, 1.1> rotate_x 35 rotate_y 20 translate <0.2, 0.9, -0.3>"),
+                     ("two_parts.obj", "rotate_z 40 translate <1, 2, 3>")):
+        text = ('camera { origin <0, 0, 9> look_at <0, 0, 0> }\n'
+                'object "m" { mesh { file "%s" transform { %s } } material { lambertian texture { solid color white } } }\n' % (mesh, xf))
+        sc = rt.parse(o, text, parity.ASSETS)
+        i, d = probe(sc)
+        m = d[128:128 + 60]
+        n_parts, outside = i[32], i[33]
+        area = lambda b: (lambda e: e[0] * e[1] + e[1] * e[2] + e[2] * e[0])(b[3:6] - b[0:3])
+        if mesh == "LinkedTorus.obj":
+            assert 2 <= n_parts <= 4
+        if n_parts:
+            assert outside == 0, mesh
+            parts = [m[6 + 6 * p:12 + 6 * p] for p in range(n_parts)]
+            assert sum(area(p) for p in parts) < 0.85 * area(m[0:6])
+            for p in parts:
+                assert np.all(p[0:3] >= m[0:3] - 1e-6) and np.all(p[3:6] <= m[3:6] + 1e-6)
+        # world boxes contain the object-space boxes' corners under the object's frame (row-vector o2w of the root node)
+        o2w = np.array(sc.desc.contents.nodes[sc.desc.contents.objects[0].shape].o2w[:]).reshape(4, 4)
+        for ob, wb in [(m[0:6], m[30:36])] + [(m[6 + 6 * p:12 + 6 * p], m[36 + 6 * p:42 + 6 * p]) for p in range(n_parts)]:
+            for c in range(8):
+                q = np.array([ob[3 * ((c >> k) & 1) + k] for k in range(3)] + [1.0])
+                w = q @ o2w
+                assert np.all(w[:3] >= wb[0:3]) and np.all(w[:3] <= wb[3:6]), (mesh, c)
