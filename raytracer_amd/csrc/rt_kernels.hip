@@ -135,8 +135,11 @@ struct rt_scene {
     void *ws = nullptr;
     Workspace own;
     bool has_csg = false, has_medium = false, has_mesh = false, has_torus = false;
-    bool ll_tail_attr_set = false;
-    bool ll_attr_set = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this scene's LL variant on its device
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this scene's LL variants of k_intersect / k_tail on its device
+    // (to the device's limit, not to this scene's need: another scene may launch the same instantiation with more); a
+    // refusal sends the scene (the tail) back to the scratch-memory lists
+    bool ll_attr_set = false, ll_tail_attr_set = false, ll_tail_ok = true;
+    int lds_limit = 65536;       // LDS a workgroup of this device may ask for
     uint32_t isect_ll_bytes = 0; // dynamic LDS of k_intersect<.., LL = true> (scene tables + every lane's interval lists); 0: the lists stay in scratch memory
     uint64_t n_mesh_tris = 0;
     uint32_t mesh_lds_bytes = 0; // dynamic LDS of k_mesh: occupancy words (+ cell starts)
@@ -397,6 +400,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
         const char *e = getenv("RT_LDS_LISTS"); // "0": the lists stay in scratch memory (measurements, tests)
         const bool off = e && !strcmp(e, "0");
         // (the kernel's static LDS - the append's words - and the allocation granularity take a little more: 1 KB each)
+        s->lds_limit = lds_limit;
         if (!off && scene_lds_bytes(s->dev) != 0u && cap <= DEV_LDS_LIST_MAX_INTERVALS && lists <= DEV_LDS_LIST_MAX_LISTS &&
             want + 1024u <= (uint64_t)lds_limit * RT_ISECT_BLOCK / (RT_LL_WAVES * 256u)) { // RT_LL_WAVES x 256 / RT_ISECT_BLOCK workgroups per CU
             s->isect_ll_bytes = (uint32_t)want;
@@ -542,16 +546,22 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     do {                                                                                                               \
         constexpr bool lists_ = (C || M) && L;                                                                         \
         if (fused) {                                                                                                   \
-            if (lists_ && s->isect_ll_bytes) {                                                                         \
-                if (!s->ll_attr_set) {                                                                                 \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 1>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);     \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 2>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);     \
-                    s->ll_attr_set = true;                                                                             \
+            if (lists_ && s->isect_ll_bytes && !s->ll_attr_set) {                                                      \
+                const hipError_t e1_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 1>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_limit);  \
+                const hipError_t e2_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 2>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_limit);  \
+                if (e1_ != hipSuccess || e2_ != hipSuccess) {                                                          \
+                    (void)hipGetLastError();                                                                           \
+                    RT_TRACE("hipFuncSetAttribute refused %d bytes of LDS: interval lists in scratch memory", s->lds_limit); \
+                    s->isect_ll_bytes = 0u;                                                                            \
+                    s->dev.lds_list_cap = s->dev.lds_list_n = 0u;                                                      \
                 }                                                                                                      \
+                s->ll_attr_set = true;                                                                                 \
+            }                                                                                                          \
+            if (lists_ && s->isect_ll_bytes)                                                                           \
                 LAUNCH_IS(C, M, T, L, true, lists_);                                                                   \
-            } else                                                                                                     \
+            else                                                                                                       \
                 LAUNCH_IS(C, M, T, L, true, false);                                                                    \
         } else {                                                                                                       \
             LAUNCH_IS(C, M, T, L, false, false);                                                                       \
@@ -688,14 +698,17 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
 #define LAUNCH_T(C, M, T, L)                                                                                           \
     do {                                                                                                               \
         constexpr bool lists_ = (C || M) && L && RT_BLOCK == RT_ISECT_BLOCK; /* one layout of the lists for both kernels */ \
-        if (lists_ && s->isect_ll_bytes) {                                                                             \
-            if (!s->ll_tail_attr_set) {                                                                                \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail<C, M, T, L, lists_>),                 \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->isect_ll_bytes);         \
-                s->ll_tail_attr_set = true;                                                                            \
+        if (lists_ && s->isect_ll_bytes && !s->ll_tail_attr_set) {                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail<C, M, T, L, lists_>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_limit) != hipSuccess) {         \
+                (void)hipGetLastError();                                                                               \
+                s->ll_tail_ok = false;                                                                                 \
             }                                                                                                          \
+            s->ll_tail_attr_set = true;                                                                                \
+        }                                                                                                              \
+        if (lists_ && s->isect_ll_bytes && s->ll_tail_ok)                                                              \
             LAUNCH_TS(C, M, T, L, lists_);                                                                             \
-        } else                                                                                                         \
+        else                                                                                                           \
             LAUNCH_TS(C, M, T, L, false);                                                                              \
     } while (0)
     switch (variant) {
