@@ -566,3 +566,27 @@ def test_flattener_bounds_and_part_boxes(rt):
                 q = np.array([ob[3 * ((c >> k) & 1) + k] for k in range(3)] + [1.0])
                 w = q @ o2w
                 assert np.all(w[:3] >= wb[0:3]) and np.all(w[:3] <= wb[3:6]), (mesh, c)
+
+
+def test_interval_algebra_is_the_same_through_both_list_stores():
+    """csg_apply (with its sort, copy and push helpers, rt_dev_shapes.h) is written once against the member names of
+    IvListT (a list per array: scratch memory on the device) and LdsList (a strided view with the interval counts packed
+    into one word: LDS on the device).  tests/helpers/lds_list_probe.cpp runs it on the host through both, over every
+    ordering of up to 3 x 3 intervals on a grid and 600 000 random pairs of lists (touching end points, full lists whose
+    results overflow), all three operations, capacities 12 and 4: same verdict, same guard and overflow counts, same
+    intervals and tags, and the neighbouring lanes' words untouched."""
+    import subprocess
+    src = os.path.join(parity.ROOT, "tests", "helpers", "lds_list_probe.cpp")
+    out = os.path.join(parity.ROOT, "tests", "helpers", "_lds_list_probe.so")
+    csrc = os.path.join(parity.ROOT, "raytracer_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("rt_device.h", "rt_dev_shapes.h", "rt_dev_math.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
+                               "-I" + os.path.join(parity.ROOT, "tools", "host_shim"), "-I" + csrc,
+                               "-I" + os.path.join(parity.ROOT, "include"), src, "-o", out])
+    lib = C.CDLL(out)
+    lib.probe_list_stores.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.probe_list_stores.restype = C.c_int
+    cases = C.c_uint64()
+    assert lib.probe_list_stores(11, 300000, C.byref(cases)) == 0
+    assert cases.value > 600000
