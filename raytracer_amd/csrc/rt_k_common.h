@@ -119,57 +119,206 @@ RT_DEV void fb_add(double *px, double r, double g, double b)
 }
 
 
-// Append with one atomic per workgroup: a single counter word takes about 90 atomics per
-// microsecond on this chip, so a per-wave atomic caps a pass at ~6 G appended rays/s; with
-// 1024-thread workgroups the counter is out of the picture.  Called by every thread of the
-// block, in block-uniform control flow.  `lds` holds blockDim.x / 64 + 1 words.
-RT_DEV uint32_t block_append(bool alive, uint32_t *counter, uint32_t *lds)
-{
-    const unsigned long long mask = __ballot(alive);
-    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    if (lane_id() == 0) lds[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < n_waves; ++w) {
-            uint32_t c = lds[w];
-            lds[w] = total;
-            total += c;
-        }
-        lds[n_waves] = total ? atomicAdd(counter, total) : 0u;
+// A queue that kernels append to lies in RT_Q_REGIONS parts of `rc` entries, each with a counter word of its own
+// (region r: positions r * rc .. r * rc + min(counter, rc) - 1; the counters `stride` words apart, on different memory
+// channels).  A single counter word takes about 90 atomics per microsecond on this chip; eight take a wave's append
+// every 32 entries.  Appenders go round the regions, so they fill evenly; one that finds its region full moves on to the
+// next (a pass appends at most as many entries as it read, RT_Q_REGIONS * rc hold them all, and a full region stays
+// full: after RT_Q_REGIONS tries every entry has a place).  Readers go over 0 .. total-1 and map an index to its
+// position (QMap).  A queue filled by position 0 .. n-1 (rt_trace_rays, the camera pass's slots) is the case rc >= n
+// with n in the first counter.
+#define RT_Q_REGIONS 8u
+struct QRegions {
+    uint32_t *cnt;
+    uint32_t rc, stride;
+};
+struct QMap {
+    uint32_t start[RT_Q_REGIONS + 1]; // index of region r's first entry; [RT_Q_REGIONS]: entries in the queue
+    uint32_t rc;
+    RT_DEV uint32_t total() const { return start[RT_Q_REGIONS]; }
+    RT_DEV uint32_t pos(uint32_t i) const
+    {
+        uint32_t first = 0u, at = 0u;
+#pragma unroll
+        for (uint32_t r = 1; r < RT_Q_REGIONS; ++r)
+            if (i >= start[r]) {
+                first = start[r];
+                at = r * rc;
+            }
+        return at + (i - first);
     }
-    __syncthreads();
-    const uint32_t at = lds[n_waves] + lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
-    __syncthreads();
-    return at;
+    // ... of entry i, one of the 64 entries i0 .. i0 + 63 that a wave reads together (i0: the same in every lane).  All
+    // but seven such blocks lie in one region: scalar work and one addition per lane
+    RT_DEV uint32_t pos(uint32_t i0, uint32_t i) const
+    {
+        const uint32_t u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+        uint32_t first = 0u, at = 0u, next = start[1];
+#pragma unroll
+        for (uint32_t r = 1; r < RT_Q_REGIONS; ++r)
+            if (u0 >= start[r]) {
+                first = start[r];
+                at = r * rc;
+                next = start[r + 1];
+            }
+        if (u0 + 63u < next) return i + (at - first);
+        return pos(i);
+    }
+};
+RT_DEV QMap qmap_load(const QRegions &q)
+{
+    QMap m;
+    m.rc = q.rc;
+    uint32_t s = 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < RT_Q_REGIONS; ++r) {
+        m.start[r] = s;
+        const uint32_t c = q.cnt[r * q.stride];
+        s += c < q.rc ? c : q.rc;
+    }
+    m.start[RT_Q_REGIONS] = s;
+    return m;
 }
 
-// Two appends with one exchange: list a and list b of the same block (a thread may be in at most one).
-// `lds` holds 2 * (blockDim.x / 64 + 1) words.
-RT_DEV void block_append2(bool a, bool b, uint32_t *counter_a, uint32_t *counter_b, uint32_t *lds, uint32_t &at_a, uint32_t &at_b)
+// Append with one atomic per workgroup and list: list a and list b of the same block (a thread may be in at most
+// one), region r0 first.  Called by every thread of the block, in block-uniform control flow.
+// `lds` holds RT_APPEND_LDS(blockDim.x) words.
+#define RT_APPEND_LDS(BLOCK) (2 * ((BLOCK) / 64 + 1 + 2 * (int)RT_Q_REGIONS))
+RT_DEV void block_append2(bool a, bool b, const QRegions &qa, const QRegions &qb, uint32_t r0, uint32_t *lds, uint32_t &at_a, uint32_t &at_b)
 {
     const unsigned long long ma = __ballot(a), mb = __ballot(b);
     const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    // per list: [w] rank of wave w's first entry; [n_waves] segments; then per segment its first rank and its
+    // position - rank (one segment, unless a region filled up under this block)
+    const uint32_t per_list = n_waves + 1u + 2u * RT_Q_REGIONS;
     if (lane_id() == 0) {
         lds[wave] = (uint32_t)__popcll(ma);
-        lds[n_waves + 1 + wave] = (uint32_t)__popcll(mb);
+        lds[per_list + wave] = (uint32_t)__popcll(mb);
     }
     __syncthreads();
-    if (threadIdx.x < 2) { // thread 0 sums list a, thread 1 list b
-        uint32_t *l = lds + threadIdx.x * (n_waves + 1);
+    if (threadIdx.x < 2) { // thread 0 places list a, thread 1 list b
+        uint32_t *l = lds + threadIdx.x * per_list;
+        const QRegions &q = threadIdx.x ? qb : qa;
         uint32_t total = 0;
         for (uint32_t w = 0; w < n_waves; ++w) {
-            uint32_t c = l[w];
+            const uint32_t c = l[w];
             l[w] = total;
             total += c;
         }
-        l[n_waves] = total ? atomicAdd(threadIdx.x ? counter_b : counter_a, total) : 0u;
+        uint32_t done = 0u, n_seg = 0u, r = r0 & (RT_Q_REGIONS - 1u);
+        for (uint32_t tries = 0; done < total && tries < RT_Q_REGIONS; ++tries) {
+            const uint32_t old = atomicAdd(q.cnt + r * q.stride, total - done);
+            const uint32_t room = old < q.rc ? q.rc - old : 0u;
+            const uint32_t take = room < total - done ? room : total - done;
+            if (take) {
+                l[n_waves + 1u + n_seg] = done;
+                l[n_waves + 1u + RT_Q_REGIONS + n_seg] = r * q.rc + old - done;
+                ++n_seg;
+            }
+            done += take;
+            r = (r + 1u) & (RT_Q_REGIONS - 1u);
+        }
+        l[n_waves] = n_seg;
     }
     __syncthreads();
     const unsigned long long lt = (1ull << lane_id()) - 1ull;
-    at_a = lds[n_waves] + lds[wave] + (uint32_t)__popcll(ma & lt);
-    at_b = lds[2 * n_waves + 1] + lds[n_waves + 1 + wave] + (uint32_t)__popcll(mb & lt);
+    const uint32_t rank[2] = {lds[wave] + (uint32_t)__popcll(ma & lt), lds[per_list + wave] + (uint32_t)__popcll(mb & lt)};
+    uint32_t at[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t *l = lds + k * per_list;
+        const uint32_t n_seg = l[n_waves];
+        uint32_t off = l[n_waves + 1u + RT_Q_REGIONS];
+        for (uint32_t sgm = 1; sgm < n_seg; ++sgm)
+            if (rank[k] >= l[n_waves + 1u + sgm]) off = l[n_waves + 1u + RT_Q_REGIONS + sgm];
+        at[k] = off + rank[k];
+    }
+    at_a = at[0];
+    at_b = at[1];
     __syncthreads();
+}
+// ... one list
+RT_DEV uint32_t block_append(bool alive, const QRegions &q, uint32_t r0, uint32_t *lds)
+{
+    uint32_t at, none;
+    block_append2(alive, false, q, q, r0, lds, at, none);
+    return at;
+}
+
+// Append per wave, without barriers (the bounce passes: there the waves of a workgroup differ most in what a round
+// costs them, and with block_append2 the other three wait for the slowest at every barrier).
+// Position of entry e of the n a wave appends at once (e: an entry's rank among them), region `r` first; `r` moves on
+// for the wave's next append.
+RT_DEV uint32_t wave_reserve(const QRegions &q, uint32_t &r, uint32_t n, uint32_t e)
+{
+    uint32_t at = 0u, done = 0u;
+    for (uint32_t tries = 0; done < n && tries < RT_Q_REGIONS; ++tries) {
+        uint32_t old = 0u;
+        if (lane_id() == 0u) old = atomicAdd(q.cnt + r * q.stride, n - done);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        const uint32_t room = old < q.rc ? q.rc - old : 0u;
+        const uint32_t take = room < n - done ? room : n - done;
+        if (e >= done && e < done + take) at = r * q.rc + old + (e - done);
+        done += take;
+        r = (r + 1u) & (RT_Q_REGIONS - 1u);
+    }
+    return at;
+}
+// One atomic per append is one returned value to wait for per round and list, and 64 times the atomics of a
+// workgroup's append when few lanes have an entry.  So a wave with fewer than RT_STAGE_DIRECT_MIN entries collects them
+// in LDS (ND doubles and NU words per entry, component k of entry e at d[k * C + e]) and moves them to the queue C at
+// a time, with coalesced stores; with more it appends them from its registers.  C == 0: no room in LDS, every append
+// from the registers.  Wave-uniform control flow; `flush(n)` stores the staged entries 0..n-1.
+#ifndef RT_STAGE_CAP
+#define RT_STAGE_CAP 32
+#endif
+#ifndef RT_STAGE_DIRECT_MIN
+#define RT_STAGE_DIRECT_MIN 24u
+#endif
+template <int C, int ND, int NU>
+struct WaveStage {
+    double *d;
+    uint32_t *u;
+    uint32_t fill;
+};
+RT_DEV void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// returns true in the lanes that have to store their entry themselves, at `at`
+template <int C, int ND, int NU, class FLUSH>
+RT_DEV bool wave_append(WaveStage<C, ND, NU> &st, bool has, const double (&vd)[ND], const uint32_t (&vu)[NU], const QRegions &q,
+                        uint32_t &r, uint32_t &at, FLUSH &&flush)
+{
+    const unsigned long long m = __ballot(has);
+    if (m == 0ull) return false;
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+    if (C == 0 || n >= RT_STAGE_DIRECT_MIN) {
+        at = wave_reserve(q, r, n, has ? rank : 0xFFFFFFFFu);
+        return has;
+    }
+    uint32_t done = 0u;
+    while (done < n) {
+        const uint32_t room = (uint32_t)C - st.fill;
+        const uint32_t take = room < n - done ? room : n - done;
+        if (has && rank >= done && rank < done + take) {
+            const uint32_t e = st.fill + rank - done;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) st.d[k * C + e] = vd[k];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) st.u[k * C + e] = vu[k];
+        }
+        st.fill += take;
+        done += take;
+        if (st.fill == (uint32_t)C) {
+            wave_lds_fence();
+            flush((uint32_t)C);
+            wave_lds_fence();
+            st.fill = 0u;
+        }
+    }
+    return false;
 }
 
 #ifndef RT_BLOCK_WIDE

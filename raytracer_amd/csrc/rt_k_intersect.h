@@ -351,16 +351,16 @@ RT_DEV bool intersect_analytic(const DevScene &sc, d3 o, d3 d, uint32_t pixel, c
 // run time; 1 / 2 - it is known to be the primary one / a ray queue, and the other half's code, pointers and registers
 // are not in the kernel (the wavefront loop launches these; 2 may also run at another occupancy, RT_QUEUE_WAVES)
 template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool FUSED, bool LL, int PQ>
-__global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *count_ptr,
+__global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevScene sc_mem, RayQueue q, const uint32_t *slots_ptr, QRegions q_regions,
                                                          PassParams pp, int32_t *primary_ids, uint32_t *guards_out,
-                                                         RayQueue mq, HitBuf mqh, uint32_t *mesh_count, RayQueue qout,
-                                                         uint32_t *count_out, double *fb, HitBuf hit, uint32_t *mesh_work, uint32_t *mesh_res_tri)
+                                                         RayQueue mq, HitBuf mqh, QRegions mesh_regions, RayQueue qout,
+                                                         QRegions out_regions, double *fb, HitBuf hit, uint32_t *mesh_work, uint32_t *mesh_res_tri)
 {
     // k_mesh's block cursors start every pass at zero (this kernel precedes it on the stream)
     if (blockIdx.x == 0 && threadIdx.x < 2 * RT_MESH_CURSORS) mesh_work[threadIdx.x * 16] = 0u;
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
-    __shared__ uint32_t append_lds[2 * (RT_ISECT_BLOCK / 64 + 1)];
+    __shared__ uint32_t append_lds[RT_APPEND_LDS(RT_ISECT_BLOCK)];
     LdsLists<RT_ISECT_BLOCK> ll;
     if (LL) {
         unsigned char *lists_lds = reinterpret_cast<unsigned char *>(scene_lds) + ((scene_lds_bytes(sc_mem) + 15u) & ~15u);
@@ -370,14 +370,89 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
         ll.tag = reinterpret_cast<uint32_t *>(lists_lds + (size_t)ll.n_lists * 2 * ll.cap_ * RT_ISECT_BLOCK * 8) + threadIdx.x;
         ll.counts = 0u;
     }
-    const uint32_t count = *count_ptr;
+    // the bounce passes append per wave (wave_append, rt_k_common.h), the few entries of a round through LDS unless
+    // that holds interval lists; the camera pass, in which most rays go on, appends per workgroup
+#ifndef RT_LL_WAVE_APPEND
+#define RT_LL_WAVE_APPEND 1
+#endif
+    constexpr bool WAVE_APPEND = FUSED && PQ == 2 && (!LL || RT_LL_WAVE_APPEND);
+    constexpr bool STAGE = WAVE_APPEND && !LL && RT_STAGE_CAP > 0;
+    constexpr int SC = STAGE ? RT_STAGE_CAP : 0;
+    __shared__ double stage_d[STAGE ? (RT_ISECT_BLOCK / 64) * (15 + 9) * SC : 1];
+    __shared__ uint32_t stage_u[STAGE ? (RT_ISECT_BLOCK / 64) * (3 + 2) * SC : 1];
+    WaveStage<SC, 15, 3> stage_m;
+    WaveStage<SC, 9, 2> stage_q;
+    stage_m.fill = stage_q.fill = 0u;
+    // where this wave's next append goes first
+    uint32_t region_m = (blockIdx.x * (RT_ISECT_BLOCK / 64) + (threadIdx.x >> 6)) & (RT_Q_REGIONS - 1u), region_q = region_m;
+    if (STAGE) {
+        const uint32_t wv = threadIdx.x >> 6;
+        stage_m.d = stage_d + wv * (15 + 9) * SC;
+        stage_q.d = stage_m.d + 15 * SC;
+        stage_m.u = stage_u + wv * (3 + 2) * SC;
+        stage_q.u = stage_m.u + 3 * SC;
+    }
+    // entries 0..n-1 of a wave's staged list go to the queue
+    auto flush_m = [&](uint32_t n) {
+        const uint32_t l = lane_id(), at = wave_reserve(mesh_regions, region_m, n, l);
+        if (l < n) {
+            const double *e = stage_m.d + l;
+            mq.o[0][at] = e[0 * SC];
+            mq.o[1][at] = e[1 * SC];
+            mq.o[2][at] = e[2 * SC];
+            mq.d[0][at] = e[3 * SC];
+            mq.d[1][at] = e[4 * SC];
+            mq.d[2][at] = e[5 * SC];
+            mq.thr[0][at] = e[6 * SC];
+            mq.thr[1][at] = e[7 * SC];
+            mq.thr[2][at] = e[8 * SC];
+            mqh.t[at] = e[9 * SC];
+            mqh.n[0][at] = e[10 * SC];
+            mqh.n[1][at] = e[11 * SC];
+            mqh.n[2][at] = e[12 * SC];
+            mqh.uv[0][at] = e[13 * SC];
+            mqh.uv[1][at] = e[14 * SC];
+            mq.slot[at] = stage_m.u[0 * SC + l];
+            mq.pixel[at] = stage_m.u[1 * SC + l];
+            mqh.obj[at] = (int32_t)stage_m.u[2 * SC + l];
+            if (mesh_res_tri) mesh_res_tri[at] = 0xFFFFFFFFu;
+        }
+    };
+    auto flush_q = [&](uint32_t n) {
+        const uint32_t l = lane_id(), at = wave_reserve(out_regions, region_q, n, l);
+        if (l < n) {
+            const double *e = stage_q.d + l;
+            qout.o[0][at] = e[0 * SC];
+            qout.o[1][at] = e[1 * SC];
+            qout.o[2][at] = e[2 * SC];
+            qout.d[0][at] = e[3 * SC];
+            qout.d[1][at] = e[4 * SC];
+            qout.d[2][at] = e[5 * SC];
+            qout.thr[0][at] = e[6 * SC];
+            qout.thr[1][at] = e[7 * SC];
+            qout.thr[2][at] = e[8 * SC];
+            qout.slot[at] = stage_q.u[0 * SC + l];
+            qout.pixel[at] = stage_q.u[1 * SC + l];
+        }
+    };
+    // the camera pass goes over the shard's slots; a ray queue is read through the map of its regions
+    const bool primary = PQ == 0 ? q.primary != 0 : PQ == 1;
+    QMap qm;
+    if (PQ != 1 && !primary) qm = qmap_load(q_regions);
+    const uint32_t count = primary ? *slots_ptr : qm.total();
     const uint32_t stride = gridDim.x * blockDim.x;
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
     Guards gd;
     for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
     gd.overflow = 0u;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
-        const uint32_t i = base + threadIdx.x;
+    // The region a workgroup's append goes to first: the next one every time; in the camera pass the one that the
+    // slots' position in the shard names (slots k * count / 8 .. fill region k: count <= 8 * rc, so none overflows, and the
+    // queues keep the order of the image.  The workgroups running at one time then share a counter word, which the camera
+    // pass's one atomic per 256 slots does not load; 4K bench frame, four in flight: 1 % better than going round)
+    uint32_t round = blockIdx.x;
+    const uint32_t per_region = (count + RT_Q_REGIONS - 1u) / RT_Q_REGIONS;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride, ++round) {
+        uint32_t i = base + threadIdx.x;
         bool wants_mesh = false, alive = false;
         d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(1.0, 1.0, 1.0);
         uint32_t pixel = 0u, slot = i;
@@ -386,13 +461,14 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
         h.n = mk3(0, 0, 0);
         h.u = h.v = 0.0;
         h.obj = -1;
-        const bool primary = PQ == 0 ? q.primary != 0 : PQ == 1;
         bool have;
         if (primary) {
             have = i < count && primary_ray(sc, q, pp, i, o, d, pixel);
         } else {
             have = i < count;
             if (have) {
+                i = qm.pos(base + (threadIdx.x & ~63u), i); // from here on: the entry's position
+                if (!FUSED) slot = i;
                 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
                 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
                 pixel = q.pixel[i];
@@ -429,8 +505,19 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
                 }
             }
         }
-        uint32_t at_m, at_q;
-        block_append2(wants_mesh, alive, mesh_count, count_out, append_lds, at_m, at_q);
+        uint32_t at_m = 0u, at_q = 0u;
+        if constexpr (WAVE_APPEND) {
+            // (from here on wants_mesh / alive: the lane stores its entry itself)
+            const double vm[15] = {o.x, o.y, o.z, d.x, d.y, d.z, thr.x, thr.y, thr.z, h.t, h.n.x, h.n.y, h.n.z, h.u, h.v};
+            const uint32_t um[3] = {slot, pixel, (uint32_t)h.obj};
+            wants_mesh = wave_append(stage_m, wants_mesh, vm, um, mesh_regions, region_m, at_m, flush_m);
+            const double vq[9] = {o.x, o.y, o.z, d.x, d.y, d.z, thr.x, thr.y, thr.z};
+            const uint32_t uq[2] = {slot, pixel};
+            alive = wave_append(stage_q, alive, vq, uq, out_regions, region_q, at_q, flush_q);
+        } else {
+            const uint32_t r0 = PQ == 1 ? base / per_region : round;
+            block_append2(wants_mesh, alive, mesh_regions, out_regions, r0, append_lds, at_m, at_q);
+        }
         if (wants_mesh) {
             mq.o[0][at_m] = o.x;
             mq.o[1][at_m] = o.y;
@@ -467,6 +554,11 @@ __global__ void __launch_bounds__(RT_ISECT_BLOCK) RT_ISECT_OCC k_intersect(DevSc
             qout.slot[at_q] = slot;
             qout.pixel[at_q] = pixel;
         }
+    }
+    if constexpr (STAGE) {
+        wave_lds_fence();
+        if (stage_m.fill) flush_m(stage_m.fill);
+        if (stage_q.fill) flush_q(stage_q.fill);
     }
     for (int k = 0; k < 5; ++k)
         if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);

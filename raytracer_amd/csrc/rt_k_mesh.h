@@ -122,7 +122,7 @@ RT_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c)
 
 template <bool KD, bool JOBS_LDS>
 __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc, RayQueue q,
-                                                      const uint32_t *mesh_count, uint32_t *work, HitBuf hit,
+                                                      QRegions mesh_regions, uint32_t *work, HitBuf hit,
                                                       int32_t *primary_ids, uint32_t refill, uint32_t block_arg, uint32_t resident_waves,
                                                       PassParams pp)
 {
@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
 
     // every wave takes blocks of 64 queue entries: its own number first, then whichever comes next (neighbouring
     // rays cost about the same, so contiguous chunks would leave whole waves with the expensive ones)
-    const uint32_t count = *mesh_count;
+    const QMap qm = qmap_load(mesh_regions); // record number -> position
+    const uint32_t count = qm.total();
     const uint32_t n_waves = gridDim.x * (RT_MESH_LANES / 64);
     const uint32_t wave = blockIdx.x * (RT_MESH_LANES / 64) + (threadIdx.x >> 6);
     const uint64_t lane_lt = (1ull << lane_id()) - 1ull;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(RT_MESH_LANES) RT_MESH_OCC k_mesh(DevScene sc,
             if (takes) {
                 const uint64_t j = cursor + (uint64_t)__popcll(empty & lane_lt);
                 if (j < block_end && j < count) {
-                    ri = (uint32_t)j; // the queue holds records, read by position
+                    ri = qm.pos((uint32_t)cursor, (uint32_t)j); // the queue holds records, read by position
                     uint32_t px_;
                     (void)fetch_ray(sc, q, pp, ri, wo, wd, px_);
                     best_obj = hit.obj[ri];
@@ -601,13 +602,15 @@ RT_DEV bool mesh_brute_wave(const DevScene &sc, d3 o, d3 d, int &best_obj, doubl
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_mesh_brute(DevScene sc, RayQueue q,
-                                                          const uint32_t *mesh_count, HitBuf hit, int32_t *primary_ids,
+                                                          QRegions mesh_regions, HitBuf hit, int32_t *primary_ids,
                                                           PassParams pp)
 {
-    const uint32_t count = *mesh_count;
+    const QMap qm = qmap_load(mesh_regions);
+    const uint32_t count = qm.total();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < count; i += n_waves) { // mesh records, by position
+    for (uint32_t idx = wave; idx < count; idx += n_waves) { // mesh records, by position
+        const uint32_t i = qm.pos(idx);
         d3 o, d;
         uint32_t px_;
         (void)fetch_ray(sc, q, pp, i, o, d, px_);

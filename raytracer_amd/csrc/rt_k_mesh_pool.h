@@ -42,7 +42,7 @@ RT_DEV double uniform_f64(double v)
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-__global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene sc, RayQueue q, const uint32_t *mesh_count,
+__global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene sc, RayQueue q, QRegions mesh_regions,
                                                                         uint32_t *work, HitBuf hit, double *res_t, uint32_t *res_tri,
                                                                         uint32_t block_arg, uint32_t resident_waves, PassParams pp)
 {
@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
     double *r_f = reinterpret_cast<double *>(pool);                        // o[3], d[3], t0, t1, ig[3]: 11 x RT_POOL_READY
     uint32_t *r_u = reinterpret_cast<uint32_t *>(r_f + 11 * RT_POOL_READY); // record number
 
-    const uint32_t count = *mesh_count;
+    const QMap qm = qmap_load(mesh_regions); // record number -> position
+    const uint32_t count = qm.total();
     const uint32_t n_waves = gridDim.x * (RT_POOL_LANES / 64);
     const uint32_t wave = uniform_u32(blockIdx.x * (RT_POOL_LANES / 64) + (threadIdx.x >> 6));
     const uint64_t lane_lt = (1ull << lane_id()) - 1ull;
@@ -145,11 +146,12 @@ __global__ void __launch_bounds__(RT_POOL_LANES) RT_POOL_OCC k_mesh_one(DevScene
                 uint32_t batch = RT_POOL_READY - nr;
                 if (batch > 64u) batch = 64u;
                 if ((uint64_t)batch > block_end - cursor) batch = (uint32_t)(block_end - cursor);
-                const uint64_t j = cursor + lane_id();
+                uint64_t j = cursor + lane_id();
                 bool found = false;
                 d3 po = mk3(0, 0, 0), pd = mk3(0, 0, 1);
                 double t0 = 0.0, t1 = 0.0;
                 if (lane_id() < batch && j < count) {
+                    j = qm.pos((uint32_t)cursor, (uint32_t)j);
                     d3 wo, wd;
                     uint32_t px_;
                     (void)fetch_ray(sc, q, pp, (uint32_t)j, wo, wd, px_);

@@ -38,11 +38,13 @@ RT_DEV bool mesh_one_finish(const DevScene &sc, d3 wo, d3 wd, double obj_t, uint
 
 // rt_trace_rays: the merged hit of mesh record j back to its ray's slot in the per-ray hit buffer (res_tri != null:
 // k_mesh_one walked the records and left the merge to mesh_one_finish)
-__global__ void k_copy_mesh_hits(DevScene sc, RayQueue mq, HitBuf mqh, const uint32_t *mesh_count, HitBuf hit, const double *res_t,
+__global__ void k_copy_mesh_hits(DevScene sc, RayQueue mq, HitBuf mqh, QRegions mesh_regions, HitBuf hit, const double *res_t,
                                  const uint32_t *res_tri)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= *mesh_count) return;
+    const QMap qm = qmap_load(mesh_regions);
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= qm.total()) return;
+    const uint32_t j = qm.pos(idx);
     const uint32_t i = mq.slot[j];
     HitRec h;
     h.t = mqh.t[j];
@@ -68,24 +70,27 @@ __global__ void k_copy_mesh_hits(DevScene sc, RayQueue mq, HitBuf mqh, const uin
 // the mesh kernel was k_mesh_one, which leaves the merge of its triangle into the record's hit to this kernel
 // (mesh_one_finish); primary_ids (depth 0 of stratum 0 only) then takes the mesh object's id here.
 template <bool SLDS>
-__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQueue qin, const uint32_t *count_in_ptr, HitBuf hit,
-                                                     RayQueue qout, uint32_t *count_out, double *fb, PassParams pp,
+__global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQueue qin, QRegions in_regions, HitBuf hit,
+                                                     RayQueue qout, QRegions out_regions, double *fb, PassParams pp,
                                                      const double *res_t, const uint32_t *res_tri, int32_t *primary_ids)
 {
     extern __shared__ double4 scene_lds[];
     const DevScene sc = scene_in_lds<SLDS>(sc_mem, reinterpret_cast<unsigned char *>(scene_lds));
-    __shared__ uint32_t append_lds[RT_BLOCK_WIDE / 64 + 1];
-    const uint32_t count = *count_in_ptr;
+    __shared__ uint32_t append_lds[RT_APPEND_LDS(RT_BLOCK_WIDE)];
+    const QMap qm = qmap_load(in_regions);
+    const uint32_t count = qm.total();
     const uint32_t stride = gridDim.x * blockDim.x;
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
-        const uint32_t i = base + threadIdx.x;
+    uint32_t round = blockIdx.x; // the region the workgroup's append goes to first: the next one every time
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride, ++round) {
+        const bool have = base + threadIdx.x < count;
+        const uint32_t i = have ? qm.pos(base + (threadIdx.x & ~63u), base + threadIdx.x) : 0u; // the record's position
         bool alive = false;
         d3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), thr = mk3(0, 0, 0);
         uint32_t slot = 0, pixel = 0;
         HitRec h;
-        h.obj = i < count ? hit.obj[i] : RT_HIT_PADDING;
-        const uint32_t tri = (res_tri && i < count) ? res_tri[i] : 0xFFFFFFFFu;
+        h.obj = have ? hit.obj[i] : RT_HIT_PADDING;
+        const uint32_t tri = (res_tri && have) ? res_tri[i] : 0xFFFFFFFFu;
         if (h.obj != RT_HIT_PADDING) {
             h.t = 0.0;
             h.n = mk3(0, 0, 0);
@@ -116,7 +121,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
                 fb_add(fb + (size_t)slot * 3, thr.x * X.x, thr.y * X.y, thr.z * X.z);
             }
         }
-        uint32_t at = block_append(alive, count_out, append_lds);
+        uint32_t at = block_append(alive, out_regions, round, append_lds);
         if (alive) {
             qout.o[0][at] = o.x;
             qout.o[1][at] = o.y;
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(RT_BLOCK_WIDE) k_shade(DevScene sc_mem, RayQue
 // as separate launches.  counts[k] gains one for every ray traced at depth k.
 // LL: the interval lists in LDS behind the scene tables, as in k_intersect (the same layout: RT_BLOCK == RT_ISECT_BLOCK)
 template <bool CSG, bool MEDIUM, bool TORUS, bool SLDS, bool LL>
-__global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, RayQueue q, const uint32_t *counts, uint32_t *counts_out,
+__global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, RayQueue q, QRegions q_regions, uint32_t *counts_out,
                                                     double *fb, PassParams pp, uint32_t *guards_out, int has_mesh,
                                                     uint32_t *lane_totals)
 {
@@ -156,7 +161,8 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
         ll.tag = reinterpret_cast<uint32_t *>(lists_lds + (size_t)ll.n_lists * 2 * ll.cap_ * RT_BLOCK * 8) + threadIdx.x;
         ll.counts = 0u;
     }
-    const uint32_t count = counts[pp.depth];
+    const QMap qm = qmap_load(q_regions);
+    const uint32_t count = qm.total();
     // a scene with meshes: one wave per path (the 64 lanes share the mesh test); without: one lane per path
     // (one lane per path, 64 paths to a wave: spreading few paths over all resident waves, 8 to 32 to a wave, as k_tail_grid
     // does, measured the same here - csg / torus 4K, fog_light 4K x 4, cornell_box 1080p within 1 % either way: without a
@@ -170,7 +176,8 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
     for (int k = 0; k < 5; ++k) gd.g[k] = 0u;
     gd.overflow = 0u;
     uint32_t my_rays = 0u, my_depth = 0u; // per_lane: segments traced beyond the first, deepest level reached
-    for (uint32_t i = unit; i < count; i += n_units) {
+    for (uint32_t idx = unit; idx < count; idx += n_units) {
+        const uint32_t i = qm.pos(idx);
         d3 o = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
         d3 d = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
         d3 thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
@@ -231,6 +238,20 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_TAIL_OCC k_tail(DevScene sc_mem, 
         for (int k = 0; k < 5; ++k)
             if (gd.g[k]) atomicAdd(&guards_out[k], gd.g[k]);
         if (gd.overflow) atomicAdd(&guards_out[5], gd.overflow);
+    }
+}
+
+// The lengths of the queues that passes first .. first + n - 1 appended to, as one word each: the rays entering the
+// next depth and the pass's mesh records (`rays`, `mesh`: the counters of depth 0; depth k's are k words on)
+__global__ void k_queue_totals(QRegions rays, QRegions mesh, uint32_t *n_rays, uint32_t *n_mesh, uint32_t first, uint32_t n)
+{
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const uint32_t depth = first + k;
+        QRegions r = rays, m = mesh;
+        r.cnt += depth + 1u;
+        m.cnt += depth;
+        n_rays[depth + 1u] = qmap_load(r).total();
+        n_mesh[depth] = qmap_load(m).total();
     }
 }
 

@@ -69,7 +69,7 @@ RT_DEV d3 bcast_d3(d3 v, int lane) { return mk3(bcast_f64(v.x, lane), bcast_f64(
 // dynamic LDS: [scene tables (scene_lds_bytes, 16-byte aligned) | job record | grid tables]
 template <bool CSG, bool MEDIUM, bool TORUS>
 __global__ void __launch_bounds__(RT_TAILG_LANES) __attribute__((amdgpu_waves_per_eu(RT_TAILG_WAVES, RT_TAILG_WAVES)))
-k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, PassParams pp, uint32_t *guards_out,
+k_tail_grid(DevScene sc_mem, RayQueue q, QRegions q_regions, double *fb, PassParams pp, uint32_t *guards_out,
             uint32_t *lane_totals)
 {
     extern __shared__ double4 tail_lds[];
@@ -109,7 +109,8 @@ k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, Pas
 #define dgz (d.z * ic_z)
 #define PF_MARK(ACC) do { } while (0)
 
-    const uint32_t count = counts[pp.depth];
+    const QMap qm = qmap_load(q_regions);
+    const uint32_t count = qm.total();
     const uint32_t n_waves = gridDim.x * (RT_TAILG_LANES / 64);
     const uint32_t wave = uniform_u32(blockIdx.x * (RT_TAILG_LANES / 64) + (threadIdx.x >> 6));
     const d3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
@@ -123,11 +124,11 @@ k_tail_grid(DevScene sc_mem, RayQueue q, const uint32_t *counts, double *fb, Pas
     uint32_t per_wave = RT_TAILG_MIN_LANES;
     while (per_wave < 64u && (uint64_t)per_wave * n_waves < count) per_wave <<= 1;
     for (uint64_t base = (uint64_t)wave * per_wave; base < count; base += (uint64_t)n_waves * per_wave) {
-        const uint64_t i = base + lane_id();
-        bool alive = lane_id() < per_wave && i < count;
+        bool alive = lane_id() < per_wave && base + lane_id() < count;
         d3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), thr = mk3(0, 0, 0);
         uint32_t slot = 0u, pixel = 0u;
         if (alive) {
+            const uint32_t i = qm.pos((uint32_t)base, (uint32_t)(base + lane_id()));
             wo = mk3(q.o[0][i], q.o[1][i], q.o[2][i]);
             wd = mk3(q.d[0][i], q.d[1][i], q.d[2][i]);
             thr = mk3(q.thr[0][i], q.thr[1][i], q.thr[2][i]);

@@ -81,6 +81,8 @@ struct Workspace {
     double *mres_t = nullptr;     // k_mesh_one's result per mesh record: t in object space,
     uint32_t *mres_tri = nullptr; // triangle (~0: none; set by k_intersect with the record); k_shade merges it
     uint32_t *d_counts = nullptr;   // 2 x (depth_cap + 2) + 2: live rays per depth, mesh-queue lengths per depth, k_tail's lane totals
+    uint32_t *d_rcnt = nullptr;     // the queues' region counters (QRegions, rt_k_common.h): [ray queues | mesh queue][region][depth], regions rstride words apart
+    uint32_t rstride = 0;
     uint32_t *d_work = nullptr;     // k_mesh's block cursors: 2 structures x RT_MESH_CURSORS, 64 bytes apart; zeroed by every k_intersect
     uint32_t *d_guards = nullptr;   // 8
     size_t cap = 0;                 // ray slots
@@ -94,7 +96,7 @@ struct Workspace {
 // per-device pointer obtained at set-up (rt_scene_create), never the name.
 // RT_NOALLOC_MAX_SLOTS, RT_NOALLOC_MAX_DEPTH: rt_api.h
 #define RT_WS_BYTES_PER_SLOT 304u // carve_workspace: 34 f64 + 8 u32 arrays (two ray queues of 80 B, mesh records of 132 + 12 B)
-#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 8192u) // 99.8 MiB
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_SLOTS * RT_WS_BYTES_PER_SLOT + 8192u + 2u * RT_Q_REGIONS * 4096u) // 99.8 MiB
 static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
 #define RT_MAX_DEVICES 64
 static void *g_noalloc_ptr[RT_MAX_DEVICES]; // device address of rt_noalloc_scratch, per device
@@ -219,11 +221,23 @@ static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Worksp
     o.mqh.obj = (int32_t *)take(n, 4);
     o.mres_tri = (uint32_t *)take(n, 4);
     o.d_counts = (uint32_t *)take(2 * ((size_t)max_depth + 2) + 2, 4);
+    o.rstride = std::max<uint32_t>(1024u, (max_depth + 2u + 63u) & ~63u); // 4 KB between the counters of one queue
+    o.d_rcnt = (uint32_t *)take(2 * (size_t)RT_Q_REGIONS * o.rstride, 4);
     o.d_work = (uint32_t *)take(2 * RT_MESH_CURSORS * 16, 4);
     o.d_guards = (uint32_t *)take(8, 4);
     o.cap = cap;
     o.depth_cap = max_depth;
     return off;
+}
+
+// the counters of a queue: table 0 - the rays entering `depth`, table 1 - the mesh records of `depth`
+static QRegions queue_regions(const Workspace &w, int table, uint32_t depth)
+{
+    QRegions r;
+    r.cnt = w.d_rcnt + (size_t)table * RT_Q_REGIONS * w.rstride + depth;
+    r.rc = (uint32_t)(((w.cap + 63) & ~(size_t)63) / RT_Q_REGIONS); // carve_workspace: the arrays hold RT_Q_REGIONS * rc entries
+    r.stride = w.rstride;
+    return r;
 }
 
 static void free_workspace(rt_scene *s)
@@ -499,16 +513,16 @@ static int check_options(const rt_options *o)
 
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
-// One depth level for the `count_ptr[0]` rays of `q`: k_intersect (nearest analytic hit; rays with no mesh to
+// One depth level for the rays of `q` (the shard's `slots_ptr[0]` slots, or the entries `q_regions` counts): k_intersect (nearest analytic hit; rays with no mesh to
 // visit are shaded there and then), then for the mesh records it queued k_mesh | k_mesh_brute (the triangles)
 // and k_shade.  Survivors of both go to `qout` / `count_out`, finished paths to `fb`.
 // fused == false (rt_trace_rays): no shading; every ray's hit record ends up in `hit_all`.
 // Returns 1 when the grid / kd walk (k_mesh) ran, 2 when k_mesh_one did, 0 otherwise.  Stage events (if any): ev_mid1 after k_intersect,
 // ev_mid2 after the mesh kernel.
 static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uint32_t live, const RayQueue &q,
-                            const uint32_t *count_ptr, uint32_t *mesh_count, const PassParams &pp, int32_t *ids,
-                            bool fused, const RayQueue &qout, uint32_t *count_out, double *fb, const HitBuf &hit_all,
-                            hipEvent_t ev_mid1, hipEvent_t ev_mid2)
+                            const uint32_t *slots_ptr, const QRegions &q_regions, const QRegions &mesh_regions,
+                            const PassParams &pp, int32_t *ids, bool fused, const RayQueue &qout,
+                            const QRegions &out_regions, double *fb, const HitBuf &hit_all, hipEvent_t ev_mid1, hipEvent_t ev_mid2)
 {
     uint64_t gb = ((uint64_t)live + RT_ISECT_BLOCK - 1) / RT_ISECT_BLOCK;
     if (gb < 1) gb = 1;
@@ -527,7 +541,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
     do {                                                                                                               \
         grid.x = std::min<uint32_t>((uint32_t)gb, isect_wgs ? isect_wgs : 256u * RT_ISECT_WAVES(C, M, T, LL, PQ) * 256u / RT_ISECT_BLOCK); \
         hipLaunchKernelGGL((k_intersect<C, M, T, L, F, LL, PQ>), grid, block, LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), st, s->dev, q, \
-                           count_ptr, pp, ids, w.d_guards, w.mq, w.mqh, mesh_count, qout, count_out, fb, hit_all, w.d_work, \
+                           slots_ptr, q_regions, pp, ids, w.d_guards, w.mq, w.mqh, mesh_regions, qout, out_regions, fb, hit_all, w.d_work, \
                            one ? w.mres_tri : nullptr);                                                                \
     } while (0)
 // the wavefront passes (fused) know which kind of queue they read: the kernel without the other kind's code
@@ -591,7 +605,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             uint64_t blocks = ((uint64_t)live * 64 + RT_BLOCK - 1) / RT_BLOCK;
             if (blocks > 256 * 8) blocks = 256 * 8;
             if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), dim3(RT_BLOCK), 0, st, s->dev, w.mq, mesh_count, w.mqh, ids, pp);
+            hipLaunchKernelGGL(k_mesh_brute, dim3((uint32_t)blocks), dim3(RT_BLOCK), 0, st, s->dev, w.mq, mesh_regions, w.mqh, ids, pp);
         } else {
             // as many waves as the chip holds: wave w starts on block w of 64 records and takes further blocks from
             // the cursors (d_work) until the queue is empty; short queues: fewer lanes per wave (block < 64)
@@ -605,7 +619,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             const bool jobs_lds = s->dev.n_jobs <= DEV_MESH_JOBS_LDS;
 #define LAUNCH_M(KD, JL, LDS_BYTES)                                                                                    \
     hipLaunchKernelGGL((k_mesh<KD, JL>), dim3((uint32_t)mb), dim3(RT_MESH_LANES), LDS_BYTES, st, s->dev, w.mq,        \
-                       mesh_count, w.d_work + (KD ? RT_MESH_CURSORS * 16 : 0), w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
+                       mesh_regions, w.d_work + (KD ? RT_MESH_CURSORS * 16 : 0), w.mqh, ids, refill, block_env, 256u * 4u * RT_MESH_WAVES, pp)
             // one launch per structure in use: each instantiation walks its own meshes and passes the others by
             // (the record carries the nearest hit from one launch to the next)
             if (one) {
@@ -616,7 +630,7 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
                 if (pb < 1) pb = 1;
                 if (pb > max_wgs) pb = max_wgs;
                 hipLaunchKernelGGL(k_mesh_one, dim3((uint32_t)pb), dim3(RT_POOL_LANES), s->mesh_pool_lds_bytes, st, s->dev, w.mq,
-                                   mesh_count, w.d_work, w.mqh, w.mres_t, w.mres_tri, block_env, 256u * 4u * RT_MESH_WAVES, pp);
+                                   mesh_regions, w.d_work, w.mqh, w.mres_t, w.mres_tri, block_env, 256u * 4u * RT_MESH_WAVES, pp);
                 walked = 2;
             } else if (s->any_grid) {
                 if (jobs_lds)
@@ -640,13 +654,13 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
             // the mesh records: hit_color + scatter, survivors appended behind k_intersect's
             if (scene_lds_bytes(s->dev) != 0u)
                 hipLaunchKernelGGL(k_shade<true>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), scene_lds_bytes(s->dev), st,
-                                   s->dev, w.mq, mesh_count, w.mqh, qout, count_out, fb, pp, one ? w.mres_t : nullptr,
+                                   s->dev, w.mq, mesh_regions, w.mqh, qout, out_regions, fb, pp, one ? w.mres_t : nullptr,
                                    one ? w.mres_tri : nullptr, ids);
             else
                 hipLaunchKernelGGL(k_shade<false>, dim3(grid_for_wide(live)), dim3(RT_BLOCK_WIDE), 0, st, s->dev, w.mq,
-                                   mesh_count, w.mqh, qout, count_out, fb, pp, one ? w.mres_t : nullptr, one ? w.mres_tri : nullptr, ids);
+                                   mesh_regions, w.mqh, qout, out_regions, fb, pp, one ? w.mres_t : nullptr, one ? w.mres_tri : nullptr, ids);
         } else {
-            hipLaunchKernelGGL(k_copy_mesh_hits, dim3((live + 255) / 256), dim3(256), 0, st, s->dev, w.mq, w.mqh, mesh_count, hit_all,
+            hipLaunchKernelGGL(k_copy_mesh_hits, dim3((live + 255) / 256), dim3(256), 0, st, s->dev, w.mq, w.mqh, mesh_regions, hit_all,
                                one ? w.mres_t : nullptr, one ? w.mres_tri : nullptr);
         }
     }
@@ -674,7 +688,7 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
         if (blocks < 1) blocks = 1;
 #define LAUNCH_TG(C, M, T)                                                                                             \
     hipLaunchKernelGGL((k_tail_grid<C, M, T>), dim3((uint32_t)blocks), dim3(RT_TAILG_LANES), s->tail_grid_lds_bytes, st, s->dev, q, \
-                       w.d_counts, d_rgb, pp, w.d_guards, lane_totals)
+                       queue_regions(w, 0, pp.depth), d_rgb, pp, w.d_guards, lane_totals)
         switch (variant) {
         case 0: LAUNCH_TG(false, false, false); break;
         case 1: LAUNCH_TG(false, false, true); break;
@@ -693,7 +707,7 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
     if (blocks < 1) blocks = 1;
 #define LAUNCH_TS(C, M, T, L, LL)                                                                                      \
     hipLaunchKernelGGL((k_tail<C, M, T, L, LL>), dim3((uint32_t)blocks), dim3(RT_BLOCK), LL ? s->isect_ll_bytes : scene_lds_bytes(s->dev), \
-                       st, s->dev, q, w.d_counts, w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
+                       st, s->dev, q, queue_regions(w, 0, pp.depth), w.d_counts, d_rgb, pp, w.d_guards, s->has_mesh ? 1 : 0, lane_totals)
 // (the variants with interval lists a second time with the lists in LDS, as k_intersect's)
 #define LAUNCH_T(C, M, T, L)                                                                                           \
     do {                                                                                                               \
@@ -803,6 +817,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                                    n_slots, d_rgb, row_major ? 1 : 0);
             } else {
                 HIP_TRY(hipMemsetAsync(w.d_counts, 0, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetAsync(w.d_rcnt, 0, 2 * (size_t)RT_Q_REGIONS * w.rstride * sizeof(uint32_t), st));
                 // depth 0 reads no ray queue: entry i is slot i and its camera ray is regenerated in place
                 RayQueue q_primary = w.q[0];
                 q_primary.primary = 1;
@@ -854,7 +869,13 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     return (uint32_t)std::min<uint64_t>(b, n_slots);
                 };
                 int cur = 0;
-                uint32_t passes = 0;
+                uint32_t passes = 0, totalled = 0; // passes launched; passes whose queue lengths k_queue_totals has summed
+                auto totals = [&]() {
+                    if (totalled < passes)
+                        hipLaunchKernelGGL(k_queue_totals, dim3(1), dim3(64), 0, st, queue_regions(w, 0, 0), queue_regions(w, 1, 0),
+                                           w.d_counts, w.d_counts + (opts->max_depth + 2), totalled, passes - totalled);
+                    totalled = passes;
+                };
                 int tail_at = -1; // depth at which the tail kernel took over
                 uint8_t *walked = s->walked.data(); // sized by ensure_host_side
                 std::memset(walked, 0, opts->max_depth + 1);
@@ -863,9 +884,9 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                     int32_t *ids = (depth == 0 && pp.stratum == 0) ? d_ids : nullptr;
                     STAGE_EV(hipEventRecord(s->evp[1 + 4 * depth], st));
                     const RayQueue &q_in = depth == 0 ? q_primary : w.q[cur];
-                    walked[depth] = (uint8_t)launch_intersect(s, w, st, live, q_in, w.d_counts + depth,
-                                                              w.d_counts + (opts->max_depth + 2) + depth, pp, ids, true,
-                                                              w.q[1 - cur], w.d_counts + depth + 1, d_rgb, w.mqh,
+                    walked[depth] = (uint8_t)launch_intersect(s, w, st, live, q_in, w.d_counts, queue_regions(w, 0, depth),
+                                                              queue_regions(w, 1, depth), pp, ids, true, w.q[1 - cur],
+                                                              queue_regions(w, 0, depth + 1), d_rgb, w.mqh,
                                                               stage_times ? s->evp[2 + 4 * depth] : nullptr,
                                                               stage_times ? s->evp[3 + 4 * depth] : nullptr);
                     STAGE_EV(hipEventRecord(s->evp[4 + 4 * depth], st));
@@ -885,6 +906,8 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                         }
                         continue;
                     }
+                    // the lengths of the queues the passes so far appended to, as one word each (what the host reads)
+                    totals();
                     // queue length of the next pass: copied back asynchronously after every pass.  The
                     // host waits for the copy of two passes ago only, so the device always has work
                     // queued across the copy's round trip; near the tail threshold (and on the last
@@ -913,6 +936,7 @@ static int render_strata(rt_scene *s, const rt_options *opts, double *d_rgb, int
                         break;
                     }
                 }
+                totals(); // (the passes queued on the hint: all of them in one launch)
                 HIP_TRY(hipMemcpyAsync(s->h_pinned, w.d_counts, (2 * (opts->max_depth + 2) + 2) * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, st)); // rays per depth, mesh-queue lengths per depth, lane totals
                 HIP_TRY(hipStreamSynchronize(st));
@@ -1761,7 +1785,11 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     HIP_TRY(hipMemcpy(stage_d, directions, n * 3 * sizeof(double), hipMemcpyHostToDevice));
     uint32_t n32 = (uint32_t)n;
     hipLaunchKernelGGL(k_rays_in, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, stage_o, stage_d, w.q[0]);
-    HIP_TRY(hipMemcpy(w.d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the rays lie at positions 0 .. n-1: a queue whose first region holds them all
+    HIP_TRY(hipMemset(w.d_rcnt, 0, 2 * (size_t)RT_Q_REGIONS * w.rstride * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(w.d_rcnt, &n32, sizeof(uint32_t), hipMemcpyHostToDevice));
+    QRegions by_position = queue_regions(w, 0, 0);
+    by_position.rc = (uint32_t)((w.cap + 63) & ~(size_t)63);
     HIP_TRY(hipMemset(w.d_guards, 0, 8 * sizeof(uint32_t)));
     PassParams pp;
     pp.seed = seed;
@@ -1770,7 +1798,6 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     pp.max_depth = 1;
     pp.force_uv = 1;
     pp.bias = 0.0;
-    HIP_TRY(hipMemset(w.d_counts + 3, 0, sizeof(uint32_t)));
     // the per-ray hit records live in the arrays of the second ray queue, which this call does not use otherwise
     HitBuf hit;
     hit.t = w.q[1].o[0];
@@ -1780,8 +1807,8 @@ extern "C" int rt_trace_rays(rt_scene *s, uint64_t seed, uint64_t n, const doubl
     hit.uv[0] = w.q[1].d[1];
     hit.uv[1] = w.q[1].d[2];
     hit.obj = (int32_t *)w.q[1].slot;
-    (void)launch_intersect(s, w, nullptr, n32, w.q[0], w.d_counts, w.d_counts + 3, pp, nullptr, false, w.q[1], w.d_counts + 4,
-                           nullptr, hit, nullptr, nullptr);
+    (void)launch_intersect(s, w, nullptr, n32, w.q[0], w.d_counts, by_position, queue_regions(w, 1, 0), pp, nullptr, false, w.q[1],
+                           queue_regions(w, 0, 1), nullptr, hit, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_hits_out, dim3((n32 + 255) / 256), dim3(256), 0, nullptr, n32, hit, stage_hits);
