@@ -131,6 +131,8 @@ RT_DEV void fb_add(double *px, double r, double g, double b)
 struct QRegions {
     uint32_t *cnt;
     uint32_t rc, stride;
+    uint32_t first_mask; // RT_Q_REGIONS - 1; 0 (RT_Q_SKEW=1, a test knob): every append tries region 0 first, so the regions
+                         // fill one after the other and most appends meet a full one
 };
 struct QMap {
     uint32_t start[RT_Q_REGIONS + 1]; // index of region r's first entry; [RT_Q_REGIONS]: entries in the queue
@@ -204,7 +206,7 @@ RT_DEV void block_append2(bool a, bool b, const QRegions &qa, const QRegions &qb
             l[w] = total;
             total += c;
         }
-        uint32_t done = 0u, n_seg = 0u, r = r0 & (RT_Q_REGIONS - 1u);
+        uint32_t done = 0u, n_seg = 0u, r = r0 & q.first_mask;
         for (uint32_t tries = 0; done < total && tries < RT_Q_REGIONS; ++tries) {
             const uint32_t old = atomicAdd(q.cnt + r * q.stride, total - done);
             const uint32_t room = old < q.rc ? q.rc - old : 0u;
@@ -251,6 +253,7 @@ RT_DEV uint32_t block_append(bool alive, const QRegions &q, uint32_t r0, uint32_
 RT_DEV uint32_t wave_reserve(const QRegions &q, uint32_t &r, uint32_t n, uint32_t e)
 {
     uint32_t at = 0u, done = 0u;
+    r &= q.first_mask;
     for (uint32_t tries = 0; done < n && tries < RT_Q_REGIONS; ++tries) {
         uint32_t old = 0u;
         if (lane_id() == 0u) old = atomicAdd(q.cnt + r * q.stride, n - done);

@@ -230,6 +230,9 @@ static size_t carve_workspace(char *base, size_t cap, uint32_t max_depth, Worksp
     return off;
 }
 
+// RT_Q_SKEW=1 (a test knob, read when a scene is created): every append tries region 0 first
+static std::atomic<int> g_q_skew{0};
+
 // the counters of a queue: table 0 - the rays entering `depth`, table 1 - the mesh records of `depth`
 static QRegions queue_regions(const Workspace &w, int table, uint32_t depth)
 {
@@ -237,6 +240,7 @@ static QRegions queue_regions(const Workspace &w, int table, uint32_t depth)
     r.cnt = w.d_rcnt + (size_t)table * RT_Q_REGIONS * w.rstride + depth;
     r.rc = (uint32_t)(((w.cap + 63) & ~(size_t)63) / RT_Q_REGIONS); // carve_workspace: the arrays hold RT_Q_REGIONS * rc entries
     r.stride = w.rstride;
+    r.first_mask = g_q_skew.load(std::memory_order_relaxed) ? 0u : RT_Q_REGIONS - 1u;
     return r;
 }
 
@@ -294,6 +298,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, rt_scene **out)
         return RT_ERR_INVALID;
     }
     *out = nullptr;
+    g_q_skew.store(getenv("RT_Q_SKEW") && atoi(getenv("RT_Q_SKEW")) != 0 ? 1 : 0, std::memory_order_relaxed);
     rt_host::FlatScene flat;
     std::string err;
     int rc = rt_host::flatten_scene(desc, flat, err);

@@ -955,6 +955,33 @@ def test_interval_lists_in_lds_and_in_scratch_agree(rt, monkeypatch):
             assert np.array_equal(out[0][5][k], out[1][5][k]), k
 
 
+def test_queue_regions_that_fill_up_pass_their_entries_on(rt, monkeypatch):
+    """The ray queues and the mesh record queue lie in eight regions with a counter word each (QRegions, rt_k_common.h);
+    appenders go round them, and one that meets a full region moves on to the next.  With RT_Q_SKEW=1 every append - per
+    workgroup in the camera pass and k_shade, per wave (staged in LDS or from the registers) in the bounce passes -
+    tries region 0 first, so the regions fill one after the other and most appends meet full ones, many of them split
+    over two regions.  The order of a queue does not reach the image: frames, ids, ray counts and traced hits are equal
+    bit for bit, at a frame size that fills the regions (a fresh scene's regions hold an eighth of its slots each)."""
+    cases = [(parity.scene_path(n), None) for n in ("mesh", "cornell_box", "csg", "fog_light")]
+    cases += [(None, fuzz_scenes.scene_text(seed, torus=False)) for seed in (3, 17)]
+    for path, text in cases:
+        o = rt.Options(width=333, height=211, samples=4, seed=9)
+        sc = rt.parse_file(o, path, parity.ASSETS) if path else rt.parse(o, text, parity.ASSETS)
+        ro, rd = _random_rays(30000, 8, np.array([0.0, 1.0, 0.0]), 3.0)
+        out = []
+        for skew in ("0", "1"):
+            monkeypatch.setenv("RT_Q_SKEW", skew)
+            dev = rt.DeviceScene(sc)
+            rgb, ids, st = dev.render(o)
+            got, _ = dev.trace_rays(ro, rd, seed=4)
+            out.append((rgb, ids, st.rays, list(st.guards), st.mesh_records, got))
+        monkeypatch.setenv("RT_Q_SKEW", "0")
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), path or text[:80]
+        assert out[0][2:5] == out[1][2:5], (path, out[0][2:5], out[1][2:5])
+        for k in ("object", "t", "n", "uv"):
+            assert np.array_equal(out[0][5][k], out[1][5][k]), k
+
+
 def test_mesh_part_boxes_only_drop_rays_that_miss(rt, monkeypatch):
     """DevMesh::part (rt_flatten.cpp): k_intersect queues a ray for the mesh walk only if it enters one of up to four boxes
     that hold every triangle between them.  A ray it drops has no triangle to meet, so the frame with the boxes equals
