@@ -388,7 +388,7 @@ def main():
         roof["traffic_source"] = traffic_note
         roof["measured"] = ("HIP events on the launch stream inside the one-frame-at-a-time leg of this run (%d steps): a launch has the GPU to "
                             "itself there.  achieved = algorithmic_bytes_per_ray x rays_per_launch / avg_launch_ms; the same kernel's average in "
-                            "profiles/r03f_alone_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --in-flight 1; k_intersect is listed there as its two instantiations, camera rays and ray queues: total time over total calls) must agree" % args.steps)
+                            "profiles/r03g_alone_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --in-flight 1; k_intersect is listed there as its two instantiations, camera rays and ray queues: total time over total calls) must agree" % args.steps)
         roof["kernel_note"] = ("the frame's dominant kernel by GPU time; k_intersect: nearest analytic hit and the shading of every ray with no "
                                "mesh to visit; the mesh stage is k_mesh_one in a scene with one mesh job (rt_k_mesh_pool.h), k_mesh otherwise")
         rays_alone = sum(st.rays for st in alone) * (world if world > 1 else 1)  # (rank 0's share times ranks: an estimate for N > 1)
