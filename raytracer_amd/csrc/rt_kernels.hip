@@ -516,6 +516,44 @@ static int check_options(const rt_options *o)
     return RT_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that wants more than the default 64 KB: as much as the device
+// allows beside the kernel's own static LDS (not the asking scene's need: another scene may launch the same instantiation
+// with more).  Some runtimes of this pool refuse limit itself when the kernel has static LDS as well, some the rest too:
+// then what has been asked for so far, whichever scene asked (the attribute belongs to the function, not to a scene).
+static bool allow_large_lds(const void *fn, int lds_limit, uint32_t need)
+{
+    static std::mutex m;
+    static std::vector<std::pair<const void *, int>> granted; // per function: the largest size set so far
+    std::lock_guard<std::mutex> lock(m);
+    int have = 0;
+    for (auto &g : granted)
+        if (g.first == fn) have = g.second;
+    if (have >= (int)need) return true;
+    hipFuncAttributes fa;
+    int stat = 0;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess)
+        stat = (int)fa.sharedSizeBytes;
+    else
+        (void)hipGetLastError();
+    const int tries[3] = {lds_limit - stat, lds_limit - stat - 1024, (int)need};
+    for (int want : tries) {
+        if (want < (int)need) continue;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess) {
+            RT_TRACE("dynamic LDS of a kernel with %d static bytes: %d allowed (device limit %d, needed %u)", stat, want, lds_limit, need);
+            bool found = false;
+            for (auto &g : granted)
+                if (g.first == fn) {
+                    g.second = want;
+                    found = true;
+                }
+            if (!found) granted.push_back({fn, want});
+            return true;
+        }
+        (void)hipGetLastError();
+    }
+    return false;
+}
+
 #define RT_BRUTE_MAX_TESTS 40000000ull // rays x triangles below which the brute-force wave kernel wins (measured)
 
 // One depth level for the rays of `q` (the shard's `slots_ptr[0]` slots, or the entries `q_regions` counts): k_intersect (nearest analytic hit; rays with no mesh to
@@ -566,13 +604,10 @@ static int launch_intersect(rt_scene *s, const Workspace &w, hipStream_t st, uin
         constexpr bool lists_ = (C || M) && L;                                                                         \
         if (fused) {                                                                                                   \
             if (lists_ && s->isect_ll_bytes && !s->ll_attr_set) {                                                      \
-                const hipError_t e1_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 1>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_limit);  \
-                const hipError_t e2_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 2>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_limit);  \
-                if (e1_ != hipSuccess || e2_ != hipSuccess) {                                                          \
-                    (void)hipGetLastError();                                                                           \
-                    RT_TRACE("hipFuncSetAttribute refused %d bytes of LDS: interval lists in scratch memory", s->lds_limit); \
+                const bool ok1_ = allow_large_lds(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 1>), s->lds_limit, s->isect_ll_bytes); \
+                const bool ok2_ = allow_large_lds(reinterpret_cast<const void *>(&k_intersect<C, M, T, L, true, lists_, 2>), s->lds_limit, s->isect_ll_bytes); \
+                if (!ok1_ || !ok2_) {                                                                                  \
+                    RT_TRACE("hipFuncSetAttribute refused %u bytes of LDS: interval lists in scratch memory", s->isect_ll_bytes); \
                     s->isect_ll_bytes = 0u;                                                                            \
                     s->dev.lds_list_cap = s->dev.lds_list_n = 0u;                                                      \
                 }                                                                                                      \
@@ -718,11 +753,8 @@ static void launch_tail(rt_scene *s, const Workspace &w, hipStream_t st, uint32_
     do {                                                                                                               \
         constexpr bool lists_ = (C || M) && L && RT_BLOCK == RT_ISECT_BLOCK; /* one layout of the lists for both kernels */ \
         if (lists_ && s->isect_ll_bytes && !s->ll_tail_attr_set) {                                                     \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail<C, M, T, L, lists_>),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_limit) != hipSuccess) {         \
-                (void)hipGetLastError();                                                                               \
+            if (!allow_large_lds(reinterpret_cast<const void *>(&k_tail<C, M, T, L, lists_>), s->lds_limit, s->isect_ll_bytes)) \
                 s->ll_tail_ok = false;                                                                                 \
-            }                                                                                                          \
             s->ll_tail_attr_set = true;                                                                                \
         }                                                                                                              \
         if (lists_ && s->isect_ll_bytes && s->ll_tail_ok)                                                              \
