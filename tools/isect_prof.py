@@ -29,7 +29,7 @@ ds._lib.rt_debug_prof(buf)
 v = list(buf)
 names = {0: "fetch / primary ray", 1: "intersect_analytic", 9: "  object loop (all kernels)", 10: "  mesh wanted (all kernels)",
          11: "  normal + uv (all kernels)", 8: "(gap before shade)", 2: "shade_one (k_intersect)", 3: "add to the pixel",
-         12: "append: ballots, barriers, atomic", 4: "stores of the appended rays", 5: "  uniform_sphere (all kernels)", 6: "  normalize (all kernels)", 7: "  texture (all kernels)"}
+         12: "append: ballots, atomics, stages + flushes", 4: "stores of rays appended from registers", 5: "  uniform_sphere (all kernels)", 6: "  normalize (all kernels)", 7: "  texture (all kernels)"}
 tot = sum(v[k] for k in (0, 1, 8, 2, 3, 12, 4))
 print("rays", st.rays)
 for k in (0, 1, 9, 10, 11, 8, 2, 5, 6, 7, 3, 12, 4):
