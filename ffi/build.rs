@@ -42,7 +42,7 @@ fn main() {
         println!("cargo:rerun-if-changed={}", csrc.join(src).display());
     }
     // every file raytracer_amd/build.py lists under HEADERS (tests/test_host_logic.py compares the two lists)
-    for header in ["rt_device.h", "rt_dev_math.h", "rt_dev_shapes.h", "rt_k_common.h", "rt_k_material.h",
+    for header in ["rt_device.h", "rt_dev_math.h", "rt_dev_shapes.h", "rt_k_common.h", "rt_queue.h", "rt_k_material.h",
                    "rt_k_intersect.h", "rt_k_mesh.h", "rt_k_mesh_grid_round.inc", "rt_k_mesh_grid_step.inc", "rt_k_mesh_pool.h",
                    "rt_k_shade.h", "rt_k_tail.h",
                    "rt_flatten.h", "rt_shard.h", "host_math.h", "host_jpeg.h", "../../include/rt_api.h",

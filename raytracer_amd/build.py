@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_amd.so")
 SOURCES = ["rt_kernels.hip", "rt_flatten.cpp", "host_scene.cpp", "host_jpeg.cpp", "rt_common.cpp"]
 HEADERS = ["rt_device.h", "rt_dev_math.h", "rt_dev_shapes.h", "rt_flatten.h", "rt_shard.h", "host_math.h", "host_jpeg.h",
-           "rt_k_common.h", "rt_k_material.h", "rt_k_intersect.h", "rt_k_mesh.h", "rt_k_mesh_grid_round.inc", "rt_k_mesh_grid_step.inc", "rt_k_mesh_pool.h", "rt_k_shade.h", "rt_k_tail.h",
+           "rt_k_common.h", "rt_queue.h", "rt_k_material.h", "rt_k_intersect.h", "rt_k_mesh.h", "rt_k_mesh_grid_round.inc", "rt_k_mesh_grid_step.inc", "rt_k_mesh_pool.h", "rt_k_shade.h", "rt_k_tail.h",
            "../../include/rt_api.h", "../../include/rt_rng.h"]
 
 # -ffp-contract: "off" keeps a*b+c as two roundings like the reference's Rust

@@ -119,67 +119,7 @@ RT_DEV void fb_add(double *px, double r, double g, double b)
 }
 
 
-// A queue that kernels append to lies in RT_Q_REGIONS parts of `rc` entries, each with a counter word of its own
-// (region r: positions r * rc .. r * rc + min(counter, rc) - 1; the counters `stride` words apart, on different memory
-// channels).  A single counter word takes about 90 atomics per microsecond on this chip; eight take a wave's append
-// every 32 entries.  Appenders go round the regions, so they fill evenly; one that finds its region full moves on to the
-// next (a pass appends at most as many entries as it read, RT_Q_REGIONS * rc hold them all, and a full region stays
-// full: after RT_Q_REGIONS tries every entry has a place).  Readers go over 0 .. total-1 and map an index to its
-// position (QMap).  A queue filled by position 0 .. n-1 (rt_trace_rays, the camera pass's slots) is the case rc >= n
-// with n in the first counter.
-#define RT_Q_REGIONS 8u
-struct QRegions {
-    uint32_t *cnt;
-    uint32_t rc, stride;
-    uint32_t first_mask; // RT_Q_REGIONS - 1; 0 (RT_Q_SKEW=1, a test knob): every append tries region 0 first, so the regions
-                         // fill one after the other and most appends meet a full one
-};
-struct QMap {
-    uint32_t start[RT_Q_REGIONS + 1]; // index of region r's first entry; [RT_Q_REGIONS]: entries in the queue
-    uint32_t rc;
-    RT_DEV uint32_t total() const { return start[RT_Q_REGIONS]; }
-    RT_DEV uint32_t pos(uint32_t i) const
-    {
-        uint32_t first = 0u, at = 0u;
-#pragma unroll
-        for (uint32_t r = 1; r < RT_Q_REGIONS; ++r)
-            if (i >= start[r]) {
-                first = start[r];
-                at = r * rc;
-            }
-        return at + (i - first);
-    }
-    // ... of entry i, one of the 64 entries i0 .. i0 + 63 that a wave reads together (i0: the same in every lane).  All
-    // but seven such blocks lie in one region: scalar work and one addition per lane
-    RT_DEV uint32_t pos(uint32_t i0, uint32_t i) const
-    {
-        const uint32_t u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
-        uint32_t first = 0u, at = 0u, next = start[1];
-#pragma unroll
-        for (uint32_t r = 1; r < RT_Q_REGIONS; ++r)
-            if (u0 >= start[r]) {
-                first = start[r];
-                at = r * rc;
-                next = start[r + 1];
-            }
-        if (u0 + 63u < next) return i + (at - first);
-        return pos(i);
-    }
-};
-RT_DEV QMap qmap_load(const QRegions &q)
-{
-    QMap m;
-    m.rc = q.rc;
-    uint32_t s = 0u;
-#pragma unroll
-    for (uint32_t r = 0; r < RT_Q_REGIONS; ++r) {
-        m.start[r] = s;
-        const uint32_t c = q.cnt[r * q.stride];
-        s += c < q.rc ? c : q.rc;
-    }
-    m.start[RT_Q_REGIONS] = s;
-    return m;
-}
+#include "rt_queue.h" // QRegions, QMap, region_reserve
 
 // Append with one atomic per workgroup and list: list a and list b of the same block (a thread may be in at most
 // one), region r0 first.  Called by every thread of the block, in block-uniform control flow.
@@ -206,19 +146,14 @@ RT_DEV void block_append2(bool a, bool b, const QRegions &qa, const QRegions &qb
             l[w] = total;
             total += c;
         }
-        uint32_t done = 0u, n_seg = 0u, r = r0 & q.first_mask;
-        for (uint32_t tries = 0; done < total && tries < RT_Q_REGIONS; ++tries) {
-            const uint32_t old = atomicAdd(q.cnt + r * q.stride, total - done);
-            const uint32_t room = old < q.rc ? q.rc - old : 0u;
-            const uint32_t take = room < total - done ? room : total - done;
-            if (take) {
-                l[n_waves + 1u + n_seg] = done;
-                l[n_waves + 1u + RT_Q_REGIONS + n_seg] = r * q.rc + old - done;
+        uint32_t n_seg = 0u, r = r0;
+        region_reserve(
+            q, r, total, [](uint32_t *word, uint32_t k) { return atomicAdd(word, k); },
+            [&](uint32_t first, uint32_t position, uint32_t) {
+                l[n_waves + 1u + n_seg] = first;
+                l[n_waves + 1u + RT_Q_REGIONS + n_seg] = position - first;
                 ++n_seg;
-            }
-            done += take;
-            r = (r + 1u) & (RT_Q_REGIONS - 1u);
-        }
+            });
         l[n_waves] = n_seg;
     }
     __syncthreads();
@@ -252,18 +187,17 @@ RT_DEV uint32_t block_append(bool alive, const QRegions &q, uint32_t r0, uint32_
 // for the wave's next append.
 RT_DEV uint32_t wave_reserve(const QRegions &q, uint32_t &r, uint32_t n, uint32_t e)
 {
-    uint32_t at = 0u, done = 0u;
-    r &= q.first_mask;
-    for (uint32_t tries = 0; done < n && tries < RT_Q_REGIONS; ++tries) {
-        uint32_t old = 0u;
-        if (lane_id() == 0u) old = atomicAdd(q.cnt + r * q.stride, n - done);
-        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-        const uint32_t room = old < q.rc ? q.rc - old : 0u;
-        const uint32_t take = room < n - done ? room : n - done;
-        if (e >= done && e < done + take) at = r * q.rc + old + (e - done);
-        done += take;
-        r = (r + 1u) & (RT_Q_REGIONS - 1u);
-    }
+    uint32_t at = 0u;
+    region_reserve(
+        q, r, n,
+        [](uint32_t *word, uint32_t k) {
+            uint32_t old = 0u;
+            if (lane_id() == 0u) old = atomicAdd(word, k);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        },
+        [&](uint32_t first, uint32_t position, uint32_t count) {
+            if (e >= first && e < first + count) at = position + (e - first);
+        });
     return at;
 }
 // One atomic per append is one returned value to wait for per round and list, and 64 times the atomics of a

@@ -590,3 +590,29 @@ def test_interval_algebra_is_the_same_through_both_list_stores():
     cases = C.c_uint64()
     assert lib.probe_list_stores(11, 300000, C.byref(cases)) == 0
     assert cases.value > 600000
+
+
+def test_queue_regions_place_and_map_every_entry():
+    """The ray queues and the mesh record queue lie in eight regions with a counter word each (rt_queue.h): appenders
+    reserve room through region_reserve - going round the regions, on to the next when one is full - and readers map
+    0 .. total-1 to positions through QMap.  tests/helpers/queue_probe.cpp runs that code on the host over random region
+    sizes, fill levels (to the last entry), append sizes and starting regions (all at region 0 as with RT_Q_SKEW=1):
+    every entry gets a position of its own inside a region, none is left without one while the regions have room, the
+    map is one to one onto the appended positions in rising order, its per-block scalar path agrees with the per-entry
+    one, and a queue filled by position maps every index to itself."""
+    import subprocess
+    src = os.path.join(parity.ROOT, "tests", "helpers", "queue_probe.cpp")
+    out = os.path.join(parity.ROOT, "tests", "helpers", "_queue_probe.so")
+    csrc = os.path.join(parity.ROOT, "raytracer_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("rt_queue.h", "rt_dev_math.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC",
+                               "-I" + os.path.join(parity.ROOT, "tools", "host_shim"), "-I" + csrc,
+                               "-I" + os.path.join(parity.ROOT, "include"), src, "-o", out])
+    lib = C.CDLL(out)
+    lib.probe_queue_regions.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.probe_queue_regions.restype = C.c_int
+    entries = C.c_uint64()
+    assert lib.probe_queue_regions(7, 4000, C.byref(entries)) == 0
+    assert entries.value > 2000000
+
