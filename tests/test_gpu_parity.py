@@ -977,7 +977,7 @@ def test_lds_interval_lists_are_granted_on_this_device():
 
 
 def test_queue_regions_that_fill_up_pass_their_entries_on(rt, monkeypatch):
-    """The ray queues and the mesh record queue lie in eight regions with a counter word each (QRegions, rt_k_common.h);
+    """The ray queues and the mesh record queue lie in eight regions with a counter word each (QRegions, rt_queue.h);
     appenders go round them, and one that meets a full region moves on to the next.  With RT_Q_SKEW=1 every append - per
     workgroup in the camera pass and k_shade, per wave (staged in LDS or from the registers) in the bounce passes -
     tries region 0 first, so the regions fill one after the other and most appends meet full ones, many of them split
