@@ -955,27 +955,6 @@ def test_interval_lists_in_lds_and_in_scratch_agree(rt, monkeypatch):
             assert np.array_equal(out[0][5][k], out[1][5][k]), k
 
 
-def test_lds_interval_lists_are_granted_on_this_device():
-    """The CSG / fog kernels with their interval lists in LDS need more than the 64 KB a workgroup gets by default
-    (hipFuncAttributeMaxDynamicSharedMemorySize; allow_large_lds, rt_kernels.hip).  A refusal is not an error - the
-    scene renders the same frame with the lists in scratch memory, a sixth slower - so nothing else notices one: the
-    runtime of some boxes refuses the device's limit itself for a kernel that also has static LDS, which round 3's
-    first builds asked for.  The library's trace (RT_DEBUG=1) says what happened."""
-    import subprocess
-    import sys
-    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
-            "import raytracer_amd as rt, parity\n"
-            "for name in ('csg', 'room', 'fog_light'):\n"
-            "    o = rt.Options(width=128, height=96, samples=1, seed=3)\n"
-            "    rt.DeviceScene(rt.parse_file(o, parity.scene_path(name), parity.ASSETS)).render(o)\n" % (parity.ROOT, parity.ROOT))
-    env = dict(os.environ, RT_DEBUG="1")
-    env.pop("RT_LDS_LISTS", None)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stderr.count("-> in LDS") == 3, r.stderr[-2000:]
-    assert "refused" not in r.stderr and "allowed" in r.stderr, r.stderr[-2000:]
-
-
 def test_queue_regions_that_fill_up_pass_their_entries_on(rt, monkeypatch):
     """The ray queues and the mesh record queue lie in eight regions with a counter word each (QRegions, rt_queue.h);
     appenders go round them, and one that meets a full region moves on to the next.  With RT_Q_SKEW=1 every append - per
